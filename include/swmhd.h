@@ -1,0 +1,125 @@
+/*
+ * swmhd.h -- C-ABI of libswmhd.so, the MI355X (gfx950) shallow-water-MHD tendency engine.
+ *
+ * This is the drop-in boundary for the hot path of writingindy/SWMHD.  The
+ * reference injects its MHD physics into Oceananigans' ShallowWaterModel as per-cell callbacks
+ *
+ *     Forcing(lorentz_force_func_x, discrete_form = true)     jacobian_formulation/SWMHD_example.jl:30-31
+ *     Forcing(div_lorentz_x,        discrete_form = true)     divergence_formulation/divergence_sw_mhd.jl:28-29
+ *
+ * with signature  func(i, j, k, grid, clock, fields)::FT .  A per-cell callback cannot launch a kernel, so
+ * every entry point here is the *whole-field* form of one such callback (or of the Oceananigans tendency
+ * kernel that calls it): it evaluates the callback for all i = 1:Nx, j = j_begin+1:j_end (k = 1) and writes
+ * the result at the same (i,j) of an output field.  INTEGRATION.md shows the Julia `ccall` glue.
+ *
+ * Conventions (identical to what Oceananigans hands the reference):
+ *   - Every field pointer is the address of the FIRST element of the halo-padded PARENT array, i.e. Julia's
+ *     `pointer(parent(field))`: shape (Nx+2Hx, Ny+2Hy, 1) column-major, x fastest.  Interior element
+ *     (i,j), 1-based, lives at  ptr[(j-1+Hy)*stride_y + (i-1+Hx)].  stride_y >= Nx+2Hx (elements).
+ *   - Locations follow the staggered C-grid: Fx / u / uh are at (Face,Center), Fy / v / vh at
+ *     (Center,Face), h / A at (Center,Center); face i lies between centres i-1 and i.
+ *   - Halos of the INPUT fields must be filled by the caller before the call (Oceananigans guarantees
+ *     this; swmhd_fill_halo_* does it for the stand-alone engine).  Halos of outputs are never written.
+ *   - All pointers are DEVICE pointers, borrowed for the duration of the enqueued work, never freed or
+ *     retained.  Calls only enqueue on `stream` (a hipStream_t passed as void*, NULL = default stream)
+ *     and return immediately.  No global state: thread-safe per stream.
+ *   - Return value: 0 on success, a positive SWMHD_E* code for argument errors, or a negative hipError_t
+ *     (negated) if the launch failed.  Nothing throws or aborts.
+ *
+ * `flags`:
+ *   SWMHD_STRICT  evaluate in the reference's exact operation order with IEEE divides and no FMA
+ *                 contraction: bit-identical to the CPU oracle (oracle/) and hence to a non-fusing
+ *                 Julia evaluation.  Default (0) is the fast path: reciprocal multiplies + FMA,
+ *                 max-norm error <= 1e-13 * max|F| (fp64), <= 2e-5 * max|F| (fp32) vs strict.
+ */
+#ifndef SWMHD_H
+#define SWMHD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWMHD_VERSION 100
+
+/* flags */
+#define SWMHD_FAST 0
+#define SWMHD_STRICT 1
+
+/* topology codes (Oceananigans.Grids.topology) */
+#define SWMHD_PERIODIC 0
+#define SWMHD_BOUNDED 1
+
+/* error codes */
+#define SWMHD_OK 0
+#define SWMHD_EINVAL 1     /* bad extents / null pointer / bad row range */
+#define SWMHD_EHALO 2      /* halo too small for the operator's stencil  */
+#define SWMHD_ENOTSUP 3    /* valid request this build does not implement */
+
+int swmhd_version(void);
+/* Human-readable text for a return code of any entry point (static storage). */
+const char *swmhd_strerror(int rc);
+
+/* ------------------------------------------------------------------------------------------------
+ * Jacobian-form Lorentz force.   Replaces lorentz_force_func_x / lorentz_force_func_y
+ * (jacobian_formulation/sw_mhd_jacobian_functions.jl:20-26, built on Bx/By :1-7 and jacobian_x/y :10-18):
+ *     Fx(i,j) = (1/ℑxᶠᵃᵃ h) * jacobian_x(i,j,A,h)    forcing on u (fcc)
+ *     Fy(i,j) = (1/ℑyᵃᶠᵃ h) * jacobian_y(i,j,A,h)    forcing on v (cfc)
+ * Stencil: A +-2 (cross-shaped), h +-1  ->  requires Hx,Hy >= 2.
+ * Rows j = j_begin+1 .. j_end (1-based) are computed; the plain form computes all rows.
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_lorentz_jacobian_f64(const double *A, const double *h, double *Fx, double *Fy,
+                               int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                               double dx, double dy, int flags, void *stream);
+int swmhd_lorentz_jacobian_f32(const float *A, const float *h, float *Fx, float *Fy,
+                               int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                               float dx, float dy, int flags, void *stream);
+int swmhd_lorentz_jacobian_rows_f64(const double *A, const double *h, double *Fx, double *Fy,
+                                    int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                    double dx, double dy, int j_begin, int j_end, int flags, void *stream);
+int swmhd_lorentz_jacobian_rows_f32(const float *A, const float *h, float *Fx, float *Fy,
+                                    int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                    float dx, float dy, int j_begin, int j_end, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Divergence-form (Maxwell-stress) Lorentz force.   Replaces div_lorentz_x / div_lorentz_y
+ * (divergence_formulation/sw_mhd_divergence_functions.jl:162-170, built on upwind_biased_product :3,
+ *  the 3rd-order biased interpolants :25-35, the four advective_lorentz_flux_* :38-132 and the
+ *  face-located Bx/By/hBx/hBy :134-148):
+ *     Fx(i,j) = (1/Az) * (δxᶠᵃᵃ lorentz_flux_hBx_bx + δyᵃᶜᵃ lorentz_flux_hBy_bx)   forcing on uh (fcc)
+ *     Fy(i,j) = (1/Az) * (δxᶜᵃᵃ lorentz_flux_hBx_by + δyᵃᶠᵃ lorentz_flux_hBy_by)   forcing on vh (cfc)
+ * Stencil: A +-3, h +-3  ->  requires Hx,Hy >= 3.
+ * topo_x/topo_y select the reference's `topology(grid, d) == Bounded` wall branches (:42-53 etc.).
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_lorentz_divergence_f64(const double *A, const double *h, double *Fx, double *Fy,
+                                 int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                 double dx, double dy, int flags, void *stream);
+int swmhd_lorentz_divergence_f32(const float *A, const float *h, float *Fx, float *Fy,
+                                 int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                 float dx, float dy, int flags, void *stream);
+int swmhd_lorentz_divergence_rows_f64(const double *A, const double *h, double *Fx, double *Fy,
+                                      int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                      double dx, double dy, int topo_x, int topo_y,
+                                      int j_begin, int j_end, int flags, void *stream);
+int swmhd_lorentz_divergence_rows_f32(const float *A, const float *h, float *Fx, float *Fy,
+                                      int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                      float dx, float dy, int topo_x, int topo_y,
+                                      int j_begin, int j_end, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Periodic halo fill (what Oceananigans' fill_halo_regions! does for topology = (Periodic, Periodic, Flat),
+ * SWMHD_example.jl:16): copies the Hx / Hy interior edge columns / rows into the opposite halos, corners
+ * included (x first, then y over the full padded width).  which: bit0 = x halos, bit1 = y halos.
+ * ---------------------------------------------------------------------------------------------- */
+#define SWMHD_HALO_X 1
+#define SWMHD_HALO_Y 2
+int swmhd_fill_halo_periodic_f64(double *field, int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                 int which, void *stream);
+int swmhd_fill_halo_periodic_f32(float *field, int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                                 int which, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWMHD_H */

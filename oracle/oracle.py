@@ -1,0 +1,102 @@
+"""ctypes/numpy front end of the CPU oracle (liboracle.so).
+
+ORACLE = test infrastructure.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module; the product package (swmhd_amd) never does and fails loudly without its HIP library.
+
+Arrays are halo-padded parents of shape (Ny+2Hy, Nx+2Hx), C-contiguous (x fastest) -- byte-for-byte the
+layout of the column-major (Nx+2Hx, Ny+2Hy, 1) OffsetArray parents Oceananigans hands to the reference's
+forcing functions (SURVEY.md section 8 conventions).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PERIODIC, BOUNDED = 0, 1
+PROBES = {name: k for k, name in enumerate(
+    ["jac_Bx", "jac_By", "jacobian_x", "jacobian_y", "lorentz_force_func_x", "lorentz_force_func_y",
+     "div_Bx", "div_By", "div_hBx", "div_hBy", "lorentz_flux_hBx_bx", "lorentz_flux_hBy_bx",
+     "lorentz_flux_hBx_by", "lorentz_flux_hBy_by", "div_lorentz_x", "div_lorentz_y"])}
+
+
+def build(force=False):
+    """Compile liboracle.so with oracle/Makefile (gcc, -ffp-contract=off)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.run(["make", "-C", _HERE] + (["-B"] if force else []), check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        for sfx, ct in (("f64", C.c_double), ("f32", C.c_float)):
+            p = C.c_void_p
+            f = getattr(_LIB, f"oracle_lorentz_jacobian_{sfx}")
+            f.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct, C.c_int]
+            f.restype = C.c_int
+            f = getattr(_LIB, f"oracle_lorentz_divergence_{sfx}")
+            f.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct, C.c_int, C.c_int, C.c_int]
+            f.restype = C.c_int
+            f = getattr(_LIB, f"oracle_probe_{sfx}")
+            f.argtypes = [C.c_int, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct,
+                          C.c_int, C.c_int]
+            f.restype = ct
+    return _LIB
+
+
+def _sfx(a):
+    if a.dtype == np.float64:
+        return "f64"
+    if a.dtype == np.float32:
+        return "f32"
+    raise TypeError(f"oracle supports float64/float32, got {a.dtype}")
+
+
+def _check(*arrs):
+    a0 = arrs[0]
+    for a in arrs:
+        assert a.flags["C_CONTIGUOUS"] and a.dtype == a0.dtype and a.shape == a0.shape, "layout mismatch"
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def lorentz_jacobian(A, h, Nx, Ny, Hx, Hy, dx, dy, nthreads=1):
+    """(Fx@fcc, Fy@cfc) = lorentz_force_func_x/y over i=1:Nx, j=1:Ny (sw_mhd_jacobian_functions.jl:20-26)."""
+    _check(A, h)
+    assert A.shape == (Ny + 2 * Hy, Nx + 2 * Hx)
+    Fx, Fy = np.zeros_like(A), np.zeros_like(A)
+    rc = getattr(lib(), f"oracle_lorentz_jacobian_{_sfx(A)}")(
+        _ptr(A), _ptr(h), _ptr(Fx), _ptr(Fy), Nx, Ny, Hx, Hy, A.shape[1], dx, dy, nthreads)
+    if rc:
+        raise ValueError(f"oracle_lorentz_jacobian rc={rc} (needs Hx,Hy >= 2)")
+    return Fx, Fy
+
+
+def lorentz_divergence(A, h, Nx, Ny, Hx, Hy, dx, dy, topo=(PERIODIC, PERIODIC), nthreads=1):
+    """(Fx@fcc, Fy@cfc) = div_lorentz_x/y over i=1:Nx, j=1:Ny (sw_mhd_divergence_functions.jl:162-170)."""
+    _check(A, h)
+    assert A.shape == (Ny + 2 * Hy, Nx + 2 * Hx)
+    Fx, Fy = np.zeros_like(A), np.zeros_like(A)
+    rc = getattr(lib(), f"oracle_lorentz_divergence_{_sfx(A)}")(
+        _ptr(A), _ptr(h), _ptr(Fx), _ptr(Fy), Nx, Ny, Hx, Hy, A.shape[1], dx, dy, topo[0], topo[1], nthreads)
+    if rc:
+        raise ValueError(f"oracle_lorentz_divergence rc={rc} (needs Hx,Hy >= 3)")
+    return Fx, Fy
+
+
+def probe(name, A, h, i, j, Nx, Ny, Hx, Hy, dx, dy, topo=(PERIODIC, PERIODIC)):
+    """Evaluate one of the reference's point functions at Julia indices (i, j)."""
+    _check(A, h)
+    return getattr(lib(), f"oracle_probe_{_sfx(A)}")(
+        PROBES[name], _ptr(A), _ptr(h), i, j, Nx, Ny, Hx, Hy, A.shape[1], dx, dy, topo[0], topo[1])

@@ -1,0 +1,12 @@
+"""swmhd_amd -- MI355X-native shallow-water MHD tendency engine (hot path of writingindy/SWMHD).
+
+The product is libswmhd.so (hand-written HIP for gfx950 behind the C-ABI in include/swmhd.h); this package is
+the thin host side: grid/field containers and whole-field forms of the reference's forcing functions.
+"""
+from . import _lib
+from .grid import RectilinearGrid, Periodic, Bounded, Flat, Center, Face
+from .fields import Field
+from .operators import lorentz_force_func, div_lorentz
+
+__all__ = ["RectilinearGrid", "Periodic", "Bounded", "Flat", "Center", "Face", "Field",
+           "lorentz_force_func", "div_lorentz", "_lib"]

@@ -1,0 +1,63 @@
+"""ctypes binding of libswmhd.so (include/swmhd.h).  The product path: fails loudly if the HIP library is
+missing -- there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswmhd.so")
+_LIB = None
+
+STRICT = 1
+FAST = 0
+PERIODIC, BOUNDED = 0, 1
+HALO_X, HALO_Y = 1, 2
+
+
+class SwmhdError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    p, i, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.swmhd_version.restype = i
+    lib.swmhd_strerror.restype = C.c_char_p
+    lib.swmhd_strerror.argtypes = [i]
+    for sfx, ft in (("f64", C.c_double), ("f32", C.c_float)):
+        for form in ("jacobian", "divergence"):
+            f = getattr(lib, f"swmhd_lorentz_{form}_{sfx}")
+            f.argtypes = [p, p, p, p, i, i, i, i, i64, ft, ft, i, p]
+            f.restype = i
+        f = getattr(lib, f"swmhd_lorentz_jacobian_rows_{sfx}")
+        f.argtypes = [p, p, p, p, i, i, i, i, i64, ft, ft, i, i, i, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_lorentz_divergence_rows_{sfx}")
+        f.argtypes = [p, p, p, p, i, i, i, i, i64, ft, ft, i, i, i, i, i, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_fill_halo_periodic_{sfx}")
+        f.argtypes = [p, i, i, i, i, i64, i, p]
+        f.restype = i
+
+
+# every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
+EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
+    f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
+        "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
+        "fill_halo_periodic")]
+
+
+def lib():
+    """Load libswmhd.so (built in-tree by __graft_entry__.build() / swmhd_amd/csrc/Makefile)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SwmhdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  swmhd_amd has no CPU fallback.")
+        _LIB = C.CDLL(LIB_PATH)
+        _declare(_LIB)
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SwmhdError(f"{what}: rc={rc}: {lib().swmhd_strerror(rc).decode()}")

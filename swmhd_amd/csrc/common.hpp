@@ -1,0 +1,46 @@
+// Shared host/device declarations for libswmhd (gfx950).  Internal: the public surface is include/swmhd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace swmhd {
+
+// Arguments of the Lorentz operator kernels.  Pointers address interior cell (i,j) = (1,1) of the
+// halo-padded parent (Julia indexing), so 0-based cell (x,y) is ptr[y*sy + x] and halo cells have
+// negative x / y.
+template <typename T>
+struct OpArgs {
+    const T *A;
+    const T *h;
+    T *Fx;
+    T *Fy;
+    int Nx, Ny, Hx, Hy;
+    long sy;
+    T dx, dy, rdx, rdy;
+    int j0, j1;  // rows [j0, j1) are computed (0-based)
+    int topo_x, topo_y;
+};
+
+// launchers, one pair per translation unit (fast: reciprocal multiplies + FMA; strict: reference op order,
+// compiled with -ffp-contract=off)
+template <typename T> hipError_t launch_lorentz_jacobian_fast(const OpArgs<T> &a, hipStream_t s);
+template <typename T> hipError_t launch_lorentz_jacobian_strict(const OpArgs<T> &a, hipStream_t s);
+template <typename T> hipError_t launch_lorentz_divergence_fast(const OpArgs<T> &a, hipStream_t s);
+template <typename T> hipError_t launch_lorentz_divergence_strict(const OpArgs<T> &a, hipStream_t s);
+
+template <typename T>
+hipError_t launch_fill_halo_periodic(T *interior, int Nx, int Ny, int Hx, int Hy, long sy, int which, hipStream_t s);
+
+// XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin
+// over the 8 XCDs; remapping gives each XCD (and its private 4 MiB L2) a contiguous run of tiles, so the
+// halo rows/columns that y-/x-adjacent tiles share are L2 hits instead of second HBM/MALL fetches.
+// Bijective for any grid size.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+    constexpr unsigned NXCD = 8;
+    unsigned q = nblk / NXCD, r = nblk % NXCD;  // XCDs [0,r) own q+1 blocks, the rest q
+    unsigned x = bid % NXCD, k = bid / NXCD;
+    unsigned base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + k;
+}
+
+}  // namespace swmhd

@@ -1,0 +1,91 @@
+// C-ABI of libswmhd.so (include/swmhd.h): argument validation + kernel launches.  No torch types, no
+// global state; every call only enqueues work on the caller's stream.
+#include "../../include/swmhd.h"
+#include "common.hpp"
+
+using namespace swmhd;
+
+namespace {
+
+inline int hiprc(hipError_t e) { return e == hipSuccess ? SWMHD_OK : -(int)e; }
+
+template <typename T>
+int lorentz_common(bool divergence, const T *A, const T *h, T *Fx, T *Fy, int Nx, int Ny, int Hx, int Hy,
+                   int64_t sy, T dx, T dy, int topo_x, int topo_y, int j_begin, int j_end, int flags, void *stream) {
+    if (!A || !h || !Fx || !Fy) return SWMHD_EINVAL;
+    if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
+    if (j_begin < 0 || j_end > Ny || j_begin > j_end) return SWMHD_EINVAL;
+    const int need = divergence ? 3 : 2;
+    if (Hx < need || Hy < need) return SWMHD_EHALO;
+    if (topo_x != SWMHD_PERIODIC || topo_y != SWMHD_PERIODIC) {
+        if ((topo_x != SWMHD_BOUNDED && topo_x != SWMHD_PERIODIC) || (topo_y != SWMHD_BOUNDED && topo_y != SWMHD_PERIODIC))
+            return SWMHD_EINVAL;
+        return SWMHD_ENOTSUP;  // Bounded wall branches: SURVEY.md 8(f) rank 3
+    }
+    if (flags & ~SWMHD_STRICT) return SWMHD_EINVAL;
+    if (j_begin == j_end) return SWMHD_OK;
+    OpArgs<T> a;
+    const long off = (long)Hy * sy + Hx;
+    a.A = A + off; a.h = h + off; a.Fx = Fx + off; a.Fy = Fy + off;
+    a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
+    a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy;
+    a.j0 = j_begin; a.j1 = j_end; a.topo_x = topo_x; a.topo_y = topo_y;
+    hipStream_t s = (hipStream_t)stream;
+    const bool strict = (flags & SWMHD_STRICT) != 0;
+    hipError_t e;
+    if (divergence) e = strict ? launch_lorentz_divergence_strict<T>(a, s) : launch_lorentz_divergence_fast<T>(a, s);
+    else e = strict ? launch_lorentz_jacobian_strict<T>(a, s) : launch_lorentz_jacobian_fast<T>(a, s);
+    return hiprc(e);
+}
+
+template <typename T>
+int halo_common(T *f, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, void *stream) {
+    if (!f || Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if (Hx > Nx || Hy > Ny) return SWMHD_EHALO;
+    if (which & ~(SWMHD_HALO_X | SWMHD_HALO_Y)) return SWMHD_EINVAL;
+    return hiprc(launch_fill_halo_periodic<T>(f + (long)Hy * sy + Hx, Nx, Ny, Hx, Hy, (long)sy, which, (hipStream_t)stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+int swmhd_version(void) { return SWMHD_VERSION; }
+
+const char *swmhd_strerror(int rc) {
+    switch (rc) {
+        case SWMHD_OK: return "success";
+        case SWMHD_EINVAL: return "invalid argument (null pointer, bad extents, stride, spacing, row range or flags)";
+        case SWMHD_EHALO: return "halo too small for the operator's stencil (Jacobian form needs 2, divergence form 3)";
+        case SWMHD_ENOTSUP: return "not supported by this build";
+        default: return rc < 0 ? hipGetErrorString((hipError_t)(-rc)) : "unknown swmhd error";
+    }
+}
+
+#define SWMHD_DEF_LORENTZ(sfx, T)                                                                                      \
+    int swmhd_lorentz_jacobian_##sfx(const T *A, const T *h, T *Fx, T *Fy, int Nx, int Ny, int Hx, int Hy,            \
+                                     int64_t sy, T dx, T dy, int flags, void *stream) {                                \
+        return lorentz_common<T>(false, A, h, Fx, Fy, Nx, Ny, Hx, Hy, sy, dx, dy, 0, 0, 0, Ny, flags, stream);         \
+    }                                                                                                                  \
+    int swmhd_lorentz_jacobian_rows_##sfx(const T *A, const T *h, T *Fx, T *Fy, int Nx, int Ny, int Hx, int Hy,       \
+                                          int64_t sy, T dx, T dy, int j0, int j1, int flags, void *stream) {           \
+        return lorentz_common<T>(false, A, h, Fx, Fy, Nx, Ny, Hx, Hy, sy, dx, dy, 0, 0, j0, j1, flags, stream);        \
+    }                                                                                                                  \
+    int swmhd_lorentz_divergence_##sfx(const T *A, const T *h, T *Fx, T *Fy, int Nx, int Ny, int Hx, int Hy,          \
+                                       int64_t sy, T dx, T dy, int flags, void *stream) {                              \
+        return lorentz_common<T>(true, A, h, Fx, Fy, Nx, Ny, Hx, Hy, sy, dx, dy, 0, 0, 0, Ny, flags, stream);          \
+    }                                                                                                                  \
+    int swmhd_lorentz_divergence_rows_##sfx(const T *A, const T *h, T *Fx, T *Fy, int Nx, int Ny, int Hx, int Hy,     \
+                                            int64_t sy, T dx, T dy, int tx, int ty, int j0, int j1, int flags,         \
+                                            void *stream) {                                                            \
+        return lorentz_common<T>(true, A, h, Fx, Fy, Nx, Ny, Hx, Hy, sy, dx, dy, tx, ty, j0, j1, flags, stream);       \
+    }                                                                                                                  \
+    int swmhd_fill_halo_periodic_##sfx(T *f, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, void *stream) {    \
+        return halo_common<T>(f, Nx, Ny, Hx, Hy, sy, which, stream);                                                   \
+    }
+
+SWMHD_DEF_LORENTZ(f64, double)
+SWMHD_DEF_LORENTZ(f32, float)
+
+}  // extern "C"

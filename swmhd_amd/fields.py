@@ -1,0 +1,69 @@
+"""Halo-padded device fields.  torch is used for device memory and streams only."""
+import numpy as np
+import torch
+
+from . import _lib
+from .grid import Center, Face
+
+_SFX = {torch.float64: "f64", torch.float32: "f32"}
+LOCS = {"u": (Face, Center), "uh": (Face, Center), "v": (Center, Face), "vh": (Center, Face),
+        "h": (Center, Center), "A": (Center, Center)}
+
+
+def _stream_ptr(stream=None):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return stream.cuda_stream
+
+
+class Field:
+    """A field on the staggered C-grid stored as its halo-padded parent, shape (Ny+2Hy, Nx+2Hx)."""
+
+    def __init__(self, grid, loc=(Center, Center), dtype=torch.float64, device="cuda", data=None):
+        self.grid, self.loc = grid, loc
+        if data is None:
+            data = torch.zeros(grid.parent_shape, dtype=dtype, device=device)
+        assert tuple(data.shape) == grid.parent_shape and data.is_contiguous()
+        self.data = data
+
+    # --- reference-style helpers -------------------------------------------------------------
+    def set(self, value):
+        """set!(field, f(x, y)) or an array/number: evaluate at this field's nodes (halos included, coordinates
+        extended linearly); call fill_halo_regions() afterwards for periodic wrap."""
+        g = self.grid
+        if callable(value):
+            X, Y = g.nodes(self.loc)
+            arr = np.asarray(value(X, Y), dtype=np.float64) + np.zeros(g.parent_shape)
+        else:
+            arr = np.asarray(value, dtype=np.float64)
+            if arr.shape == (g.Ny, g.Nx):
+                full = np.zeros(g.parent_shape)
+                full[g.interior] = arr
+                arr = full
+            else:
+                arr = arr + np.zeros(g.parent_shape)
+        self.data.copy_(torch.from_numpy(arr).to(self.data.dtype))
+        return self
+
+    def fill_halo_regions(self, stream=None):
+        """Periodic halo fill on the device (swmhd_fill_halo_periodic_*)."""
+        g = self.grid
+        which = (_lib.HALO_X if g.topology[0] == "Periodic" else 0) | (_lib.HALO_Y if g.topology[1] == "Periodic" else 0)
+        f = getattr(_lib.lib(), f"swmhd_fill_halo_periodic_{_SFX[self.data.dtype]}")
+        _lib.check(f(self.data.data_ptr(), g.Nx, g.Ny, g.Hx, g.Hy, self.stride_y, which, _stream_ptr(stream)),
+                   "swmhd_fill_halo_periodic")
+        return self
+
+    @property
+    def stride_y(self):
+        return self.data.stride(0)
+
+    @property
+    def ptr(self):
+        return self.data.data_ptr()
+
+    def interior(self):
+        return self.data[self.grid.interior]
+
+    def numpy(self):
+        return self.data.detach().cpu().numpy()

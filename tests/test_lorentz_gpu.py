@@ -1,0 +1,166 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs.
+
+Bars:
+  SWMHD_STRICT  -> bit-identical to the oracle (same operation order, IEEE divides, no FMA contraction)
+  fast (default)-> max|dF| <= 1e-13 * max|F| (fp64),  <= 2e-5 * max|F| (fp32)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = {np.float64: 1e-13, np.float32: 2e-5}
+
+
+def _fields(S, Nx, Ny, H, A, h, d=(0.37, 0.41)):
+    g = S.RectilinearGrid(size=(Nx, Ny), x=(0, d[0] * Nx), y=(0, d[1] * Ny), halo=(H, H))
+    tdt = torch.float64 if A.dtype == np.float64 else torch.float32
+    fa = S.Field(g, dtype=tdt, data=torch.from_numpy(A).cuda())
+    fh = S.Field(g, dtype=tdt, data=torch.from_numpy(h).cuda())
+    return g, {"A": fa, "h": fh}
+
+
+def _run(S, form, g, fields, **kw):
+    fn = S.lorentz_force_func if form == "jacobian" else S.div_lorentz
+    Fx, Fy = fn(g, fields, **kw)
+    torch.cuda.synchronize()
+    return Fx.numpy(), Fy.numpy()
+
+
+def _oracle(O, form, A, h, g):
+    fn = O.lorentz_jacobian if form == "jacobian" else O.lorentz_divergence
+    return fn(A, h, g.Nx, g.Ny, g.Hx, g.Hy, g.dx, g.dy, nthreads=8)
+
+
+SHAPES = [(64, 16), (100, 37), (5, 4), (130, 70), (256, 256), (513, 33), (1, 1)]
+
+
+@pytest.mark.parametrize("form", ["jacobian", "divergence"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_strict_is_bitwise_and_fast_within_tolerance(swmhd, oracle, form, dtype, shape):
+    Nx, Ny = shape
+    H = 3
+    if Nx < H or Ny < H:   # periodic fill needs H <= N; tiny grids get non-periodic random halos instead
+        A, h = Hh.random_case(Nx, Ny, H, H, 100 + Nx, dtype, periodic=False)
+    else:
+        A, h = Hh.random_case(Nx, Ny, H, H, 100 + Nx, dtype)
+    g, f = _fields(swmhd, Nx, Ny, H, A, h)
+    want = _oracle(oracle, form, A, h, g)
+    got = _run(swmhd, form, g, f, strict=True)
+    I = g.interior
+    for w, q in zip(want, got):
+        assert np.array_equal(w[I], q[I]), f"strict {form} differs from oracle: max {np.abs(w[I]-q[I]).max()}"
+    fast = _run(swmhd, form, g, f, strict=False)
+    for w, q in zip(want, fast):
+        assert np.abs(w[I] - q[I]).max() <= TOL[dtype] * max(np.abs(w[I]).max(), 1e-300)
+
+
+@pytest.mark.parametrize("form", ["jacobian", "divergence"])
+def test_outputs_outside_interior_untouched_and_row_ranges(swmhd, oracle, form):
+    Nx, Ny, H = 70, 50, 3
+    A, h = Hh.random_case(Nx, Ny, H, H, 9)
+    g, f = _fields(swmhd, Nx, Ny, H, A, h)
+    want = _oracle(oracle, form, A, h, g)
+    sentinel = -777.25
+    out = (swmhd.Field(g), swmhd.Field(g))
+    for o in out:
+        o.data.fill_(sentinel)
+    got = _run(swmhd, form, g, f, out=out, strict=True, rows=(13, 31))
+    for w, q in zip(want, got):
+        assert np.array_equal(q[H + 13:H + 31, H:H + Nx], w[H + 13:H + 31, H:H + Nx])
+        mask = np.ones_like(q, dtype=bool)
+        mask[H + 13:H + 31, H:H + Nx] = False
+        assert np.all(q[mask] == sentinel), "kernel wrote outside the requested rows / into halos"
+
+
+@pytest.mark.parametrize("name", ["gaussian_128", "two_gaussians_64"])
+def test_golden_fixtures(swmhd, name):
+    """Committed fixtures (restatement-generated, tests/golden/make_golden.py) -- no oracle call here."""
+    z = np.load(os.path.join(GOLD, name + ".npz"))
+    A, h, d = z["A"], z["h"], float(z["d"])
+    N = A.shape[0] - 6
+    g, f = _fields(swmhd, N, N, 3, np.ascontiguousarray(A), np.ascontiguousarray(h), d=(d, d))
+    Jx, Jy = _run(swmhd, "jacobian", g, f, strict=True)
+    Dx, Dy = _run(swmhd, "divergence", g, f, strict=True)
+    I = g.interior
+    for got, key in ((Jx, "Jx"), (Jy, "Jy"), (Dx, "Dx"), (Dy, "Dy")):
+        assert np.array_equal(got[I], z[key][I]), key
+
+
+def test_analytic_pin_through_the_hip_path(swmhd):
+    """test_formulations.jl:14-15,205-210 evaluated by the HIP kernels: 2nd-order convergence to (-4x,-4y)exp(-2r^2)."""
+    errs = []
+    for N in (64, 128, 256, 512):
+        A, h, d, ex, ey = Hh.gaussian_case(N, 3)
+        g, f = _fields(swmhd, N, N, 3, A, h, d=(d, d))
+        I = g.interior
+        Jx, Jy = _run(swmhd, "jacobian", g, f)
+        Dx, Dy = _run(swmhd, "divergence", g, f)
+        errs.append([np.abs(Jx - ex)[I].max(), np.abs(Jy - ey)[I].max(), np.abs(Dx - ex)[I].max(), np.abs(Dy - ey)[I].max()])
+    E = np.array(errs)
+    for c in range(4):
+        slope = -np.polyfit(np.log10([64, 128, 256, 512]), np.log10(E[:, c]), 1)[0]
+        assert 1.9 < slope < 2.1
+    assert abs(E[0, 0] - 6.554741068160697e-2) < 1e-12 and abs(E[0, 2] - 8.998312934496977e-2) < 1e-12
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_periodic_halo_fill(swmhd, dtype):
+    Nx, Ny, H = 37, 21, 3
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, 1), y=(0, 1), halo=(H, H))
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(g.parent_shape)
+    f = swmhd.Field(g, dtype=dtype, data=torch.from_numpy(a).to(dtype).cuda())
+    f.fill_halo_regions()
+    torch.cuda.synchronize()
+    want = Hh.fill_halo_periodic(a.astype(np.float64 if dtype == torch.float64 else np.float32), Nx, Ny, H, H)
+    assert np.array_equal(f.numpy(), want)
+
+
+@pytest.mark.parametrize("form", ["jacobian", "divergence"])
+def test_full_size_properties_4096(swmhd, form):
+    """BASELINE size (4096^2, too big for the oracle in seconds): size-independent properties.
+    (1) quadratic scaling: F(2A) == 4 F(A) bitwise (power-of-two scaling commutes with every rounding);
+    (2) periodic shift equivariance, bitwise; (3) fast vs strict within tolerance."""
+    N, H = 4096, 3
+    g = swmhd.RectilinearGrid(size=(N, N), x=(-np.pi, np.pi), y=(-10, 10), halo=(H, H))
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    A = swmhd.Field(g)
+    h = swmhd.Field(g)
+    A.data.normal_(generator=gen)
+    h.data.uniform_(1.0, 1.3, generator=gen)
+    A.fill_halo_regions(); h.fill_halo_regions()
+    fn = swmhd.lorentz_force_func if form == "jacobian" else swmhd.div_lorentz
+    Fx, Fy = fn(g, {"A": A, "h": h}, strict=True)
+    A2 = swmhd.Field(g, data=A.data * 2)
+    Gx, Gy = fn(g, {"A": A2, "h": h}, strict=True)
+    I = g.interior
+    assert torch.equal(Gx.data[I], 4 * Fx.data[I]) and torch.equal(Gy.data[I], 4 * Fy.data[I])
+    sy_, sx_ = 1000, 37
+    As = swmhd.Field(g); hs = swmhd.Field(g)
+    As.data[I] = torch.roll(A.data[I], (sy_, sx_), (0, 1)); hs.data[I] = torch.roll(h.data[I], (sy_, sx_), (0, 1))
+    As.fill_halo_regions(); hs.fill_halo_regions()
+    Sx, Sy = fn(g, {"A": As, "h": hs}, strict=True)
+    assert torch.equal(Sx.data[I], torch.roll(Fx.data[I], (sy_, sx_), (0, 1)))
+    assert torch.equal(Sy.data[I], torch.roll(Fy.data[I], (sy_, sx_), (0, 1)))
+    Qx, Qy = fn(g, {"A": A, "h": h}, strict=False)
+    for s, q in ((Fx, Qx), (Fy, Qy)):
+        assert (s.data[I] - q.data[I]).abs().max().item() <= 1e-13 * s.data[I].abs().max().item()
+    assert torch.isfinite(Fx.data[I]).all() and Fx.data[I].abs().max().item() > 0
+
+
+def test_error_codes_on_device_pointers(swmhd):
+    g = swmhd.RectilinearGrid(size=(16, 16), x=(0, 1), y=(0, 1), halo=(2, 2))
+    A, h = swmhd.Field(g), swmhd.Field(g)
+    h.data.fill_(1.0)
+    swmhd.lorentz_force_func(g, {"A": A, "h": h})          # halo 2 is enough for the Jacobian form
+    with pytest.raises(swmhd._lib.SwmhdError, match="halo"):
+        swmhd.div_lorentz(g, {"A": A, "h": h})             # ... but not for the divergence form
+    torch.cuda.synchronize()
