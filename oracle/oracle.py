@@ -46,6 +46,15 @@ def lib():
             f = getattr(_LIB, f"oracle_lorentz_divergence_{sfx}")
             f.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct, C.c_int, C.c_int, C.c_int]
             f.restype = C.c_int
+            f = getattr(_LIB, f"oracle_tendencies_{sfx}")
+            f.argtypes = [p] * 8 + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, C.c_int]
+            f.restype = C.c_int
+            f = getattr(_LIB, f"oracle_fill_halo_periodic_{sfx}")
+            f.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long]
+            f.restype = None
+            f = getattr(_LIB, f"oracle_time_step_{sfx}")
+            f.argtypes = [p] * 6 + [C.c_long] + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, ct, C.c_int]
+            f.restype = C.c_int
             f = getattr(_LIB, f"oracle_probe_{sfx}")
             f.argtypes = [C.c_int, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct,
                           C.c_int, C.c_int]
@@ -100,3 +109,43 @@ def probe(name, A, h, i, j, Nx, Ny, Hx, Hy, dx, dy, topo=(PERIODIC, PERIODIC)):
     _check(A, h)
     return getattr(lib(), f"oracle_probe_{_sfx(A)}")(
         PROBES[name], _ptr(A), _ptr(h), i, j, Nx, Ny, Hx, Hy, A.shape[1], dx, dy, topo[0], topo[1])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Base shallow-water RHS + RK3 (oracle/sw_rhs.inc) -- PARITY UNPINNED restatement of Oceananigans' ShallowWaterModel
+# ------------------------------------------------------------------------------------------------------------
+CONSERVATIVE, VECTOR_INVARIANT = 0, 1
+LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = 0, 1, 2
+
+
+def tendencies(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, formulation, lorentz, g=9.81, f=1.0, nthreads=1):
+    """(G_q1, G_q2, G_h, G_A) for q = (uh, vh) [formulation 0] or (u, v) [formulation 1]; halos must be filled."""
+    _check(q1, q2, h, A)
+    assert A.shape == (Ny + 2 * Hy, Nx + 2 * Hx)
+    G = [np.zeros_like(A) for _ in range(4)]
+    rc = getattr(lib(), f"oracle_tendencies_{_sfx(A)}")(
+        _ptr(q1), _ptr(q2), _ptr(h), _ptr(A), *[_ptr(x) for x in G], Nx, Ny, Hx, Hy, A.shape[1], dx, dy, g, f,
+        formulation, lorentz, nthreads)
+    if rc:
+        raise ValueError(f"oracle_tendencies rc={rc}")
+    return tuple(G)
+
+
+def fill_halo_periodic(a, Nx, Ny, Hx, Hy):
+    _check(a)
+    getattr(lib(), f"oracle_fill_halo_periodic_{_sfx(a)}")(_ptr(a), Nx, Ny, Hx, Hy, a.shape[1])
+    return a
+
+
+def time_step(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, dt, formulation, lorentz, g=9.81, f=1.0, nthreads=1, work=None):
+    """One RK3 step in place (RungeKutta3: γ = 8/15, 5/12, 3/4; ζ = -17/60, -5/12).  Halos filled on entry and exit."""
+    _check(q1, q2, h, A)
+    n = A.size
+    if work is None:
+        work = (np.zeros(4 * n, A.dtype), np.zeros(4 * n, A.dtype))
+    rc = getattr(lib(), f"oracle_time_step_{_sfx(A)}")(
+        _ptr(q1), _ptr(q2), _ptr(h), _ptr(A), _ptr(work[0]), _ptr(work[1]), n, Nx, Ny, Hx, Hy, A.shape[1], dx, dy, g, f,
+        formulation, lorentz, dt, nthreads)
+    if rc:
+        raise ValueError(f"oracle_time_step rc={rc}")
+    return work

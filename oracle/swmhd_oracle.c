@@ -19,11 +19,13 @@
 #define REAL double
 #define SFX _f64
 #include "lorentz_ops.inc"
+#include "sw_rhs.inc"
 #undef REAL
 #undef SFX
 
 #define REAL float
 #define SFX _f32
 #include "lorentz_ops.inc"
+#include "sw_rhs.inc"
 #undef REAL
 #undef SFX
