@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the shallow-water-MHD tendency engine on MI355X.
 
-Contract (see the task statement):  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
-Metric: BASELINE.json's "Mcell-steps/sec (fp64) on 4096^2 periodic grid".  Workload: BASELINE config 3
-(4096x4096, Jacobian formulation, Bickley-jet-style h/u, fp64), inputs resident in HBM before the timed region.
-
-Round-1 state of the "step": one evaluation of the Jacobian-form Lorentz-force operator over the whole grid
-(the reference's hot path, sw_mhd_jacobian_functions.jl:1-26) -- `config.step` says so.  Weak scaling for N > 1:
-every rank owns a 4096 x 4096 y-slab of a 4096 x (4096 N) periodic domain.
+Contract:  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
+Metric (BASELINE.json): Mcell-steps/sec (fp64) on a 4096^2 periodic grid.  One step = one full RK3 time step of the
+model the reference builds (SWMHD_example.jl:21-42): 3 x {fused tendency evaluation incl. the Jacobian-form Lorentz
+force, RK3 substep of 4 fields, halo fill}.  Workload: BASELINE config 3 (4096x4096, Jacobian formulation = vector-
+invariant u,v,h + tracer A, Bickley-jet-style h/u, fp64), synthetic initial condition resident in HBM before timing.
+Weak scaling for N > 1: every rank owns a 4096 x 4096 y-slab of a 4096 x (4096 N) periodic domain; halo rows move by
+RCCL send/recv between ring neighbours, overlapped with the interior rows on a second stream.
 """
 import argparse
 import json
@@ -22,84 +22,93 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-OP_BYTES_PER_CELL = 32         # read A,h + write Fx,Fy, fp64
+TEND_BYTES_PER_CELL = 64       # read u,v,h,A + write 4 tendencies, fp64
+STEP_BYTES_PER_CELL = 544      # 3*64 + 96 + 128 + 128
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=10)
-    p.add_argument("--n", type=int, default=4096, help="grid edge (default: BASELINE config 3)")
-    p.add_argument("--form", default="jacobian", choices=["jacobian", "divergence"])
-    p.add_argument("--strict", action="store_true", help="time the reference-order (bitwise) kernels instead of the fast ones")
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--size", dest="n", type=int, default=4096, help="grid edge per GPU (default: BASELINE config 3)")
+    p.add_argument("--formulation", default="VectorInvariant", choices=["VectorInvariant", "Conservative"])
+    p.add_argument("--strict", action="store_true", help="time the oracle-order (bitwise) kernels instead of the fast ones")
+    p.add_argument("--dt", type=float, default=1e-4)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    p.add_argument("--backend", default="nccl")
     return p.parse_args()
 
 
-def cpu_baseline(args, cfg, g_full):
-    """Oracle (C restatement of the reference's per-cell functions, same cost structure) on the host cores, on a
-    bounded sample of the same workload: the first rows of the 4096^2 grid, repeated until the time budget is used."""
+def build_model(S, args, rank, world, n, ny_local=None):
+    from swmhd_amd import configs
+    cfg = configs.config3_bickley() if args.formulation == "VectorInvariant" else configs.config4_two_gaussians()
+    y0, y1 = cfg["domain"]["y"]
+    dec = S.SlabDecomposition(n * world, world, rank)
+    g = dec.local_grid(S.RectilinearGrid, n, x=cfg["domain"]["x"], y=(y0, y0 + (y1 - y0) * world))
+    return cfg, dec, g
+
+
+def cpu_baseline(args, cfg):
+    """The oracle's RK3 step (C restatement: the reference's per-cell Lorentz functions with their unshared composition +
+    the restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 512 x 256 periodic
+    block cut from the centre of the configuration, stepped until the time budget is used."""
     from oracle import oracle as O
     import swmhd_amd as S
-    cores = os.cpu_count() or 1
-    Ny_s = 256
-    g = S.RectilinearGrid(size=(args.n, Ny_s), x=cfg["domain"]["x"], y=cfg["domain"]["y"], halo=(3, 3),
-                          j_offset=args.n // 2 - Ny_s // 2, Ny_global=args.n)
-    X, Y = g.nodes(("Center", "Center"))
-    A = np.ascontiguousarray(cfg["A"](X, Y)); h = np.ascontiguousarray(cfg["h"](X, Y) + 0 * X)
-    fn = O.lorentz_jacobian if args.form == "jacobian" else O.lorentz_divergence
-    fn(A, h, g.Nx, g.Ny, 3, 3, g.dx, g.dy, nthreads=cores)  # warm
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)   # the box's CPU share for one GPU
+    Nx, Ny = 512, 256
+    x0, x1 = cfg["domain"]["x"]; y0, y1 = cfg["domain"]["y"]
+    dx, dy = (x1 - x0) / args.n, (y1 - y0) / args.n
+    g = S.RectilinearGrid(size=(Nx, Ny), x=(-Nx * dx / 2, Nx * dx / 2), y=(-Ny * dy / 2, Ny * dy / 2))
+    form = 1 if args.formulation == "VectorInvariant" else 0
+    names = [("u", ("Face", "Center")), ("v", ("Center", "Face")), ("h", ("Center", "Center")), ("A", ("Center", "Center"))]
+    q = []
+    for nm, loc in names:
+        X, Y = g.nodes(loc)
+        q.append(O.fill_halo_periodic(np.ascontiguousarray(cfg[nm](X, Y) + 0 * X), Nx, Ny, 3, 3))
+    work = O.time_step(*q, Nx, Ny, 3, 3, dx, dy, args.dt, form, 2 - form, nthreads=cores)   # warm
     t0 = time.perf_counter(); reps = 0
     while time.perf_counter() - t0 < args.cpu_seconds:
-        fn(A, h, g.Nx, g.Ny, 3, 3, g.dx, g.dy, nthreads=cores); reps += 1
+        O.time_step(*q, Nx, Ny, 3, 3, dx, dy, args.dt, form, 2 - form, nthreads=cores, work=work); reps += 1
     dt = time.perf_counter() - t0
-    return {"value": g.Nx * g.Ny * reps / dt / 1e6, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{args.n}x{Ny_s} centre rows of the {args.n}^2 workload, {reps} reps, C oracle with the "
-                      f"reference's unshared per-cell composition, OpenMP over {cores} threads"}
+    return {"value": Nx * Ny * reps / dt / 1e6, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{Nx}x{Ny} periodic block at the workload's dx,dy and fields, {reps} RK3 steps; C oracle (reference's "
+                      f"unshared per-cell Lorentz composition + restated Oceananigans RHS), OpenMP over {cores} threads; "
+                      "Julia/Oceananigans are not available on the box"}
 
 
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, **kw)
 
     import swmhd_amd as S
-    from swmhd_amd import configs
-    cfg = configs.config3_bickley()
     N = args.n
-    # weak scaling: rank r owns rows [r*N, (r+1)*N) of an N x (N*world) domain (y extent scales with world)
-    y0, y1 = cfg["domain"]["y"]
-    g = S.RectilinearGrid(size=(N, N), x=cfg["domain"]["x"], y=(y0, y0 + (y1 - y0) * world), halo=(3, 3),
-                          j_offset=rank * N, Ny_global=N * world)
-    A, h = S.Field(g), S.Field(g)
-    A.set(cfg["A"]); h.set(lambda X, Y: cfg["h"](X, Y) + 0 * X)
-    A.fill_halo_regions(); h.fill_halo_regions()     # x wrap (+ y wrap; at N>1 the slab halos come from set())
-    out = (S.Field(g, (S.Face, S.Center)), S.Field(g, (S.Center, S.Face)))
-    fn = S.lorentz_force_func if args.form == "jacobian" else S.div_lorentz
-    fields = {"A": A, "h": h}
-
-    def step():
-        fn(g, fields, out=out, strict=args.strict)
+    cfg, dec, g = build_model(S, args, rank, world, N)
+    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=args.formulation, strict=args.strict, decomp=dec)
+    n1, n2 = m.names[:2]
+    if args.formulation == "VectorInvariant":
+        m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
+    else:
+        m.set(**{n1: cfg["u"], n2: cfg["v"], "h": cfg["h"], "A": cfg["A"]})
 
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
+        m.time_step(args.dt)
+    m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m.tendency_events = [] if world == 1 else None
     t0 = time.perf_counter()
-    ev0.record()
     for _ in range(args.steps):
-        step()
-    ev1.record()
-    torch.cuda.synchronize()
+        m.time_step(args.dt)
+    m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -107,25 +116,35 @@ def main():
         t = torch.tensor([wall], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
-    kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream, live, over the timed region
+    finite = all(torch.isfinite(f.data).all().item() for f in m.fields)
 
     if rank == 0:
         cells = N * N
         value = cells * world * args.steps / wall / 1e6
-        achieved = OP_BYTES_PER_CELL * cells / (kern_ms * 1e-3) / 1e9
         line = {
             "metric": "Mcell-steps/sec (fp64) on 4096^2 periodic grid", "value": value, "unit": "Mcell-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N}x{N} periodic, {args.form} formulation, Bickley-jet h/u + current-sheet A (BASELINE config 3)",
-                       "step": f"one whole-grid evaluation of the {args.form}-form Lorentz force ({'strict' if args.strict else 'fast'} kernel)",
-                       "decomposition": f"y-slabs x{world}, {N}x{N} cells per GPU"},
-            "roofline": {"bound": "hbm", "kernel": f"k_lorentz_{args.form}", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "algorithmic_bytes_per_launch": OP_BYTES_PER_CELL * cells, "avg_launch_ms": kern_ms},
+            "config": {"workload": f"{N}x{N} cells per GPU, periodic, {args.formulation} formulation + "
+                                   f"{'Jacobian' if args.formulation == 'VectorInvariant' else 'divergence'}-form Lorentz forcing, "
+                                   "Bickley-jet h/u + current-sheet A (BASELINE config 3)" if args.formulation == "VectorInvariant"
+                                   else f"{N}x{N} cells per GPU, periodic, Conservative formulation + divergence-form Lorentz forcing, two-Gaussian A (BASELINE config 4 ICs)",
+                       "step": "one RK3 time step = 3 x (fused tendency kernel + RK3 substep of 4 fields + halo fill)",
+                       "kernels": "strict (oracle-order)" if args.strict else "fast",
+                       "decomposition": f"y-slabs x{world} (ring halo exchange over RCCL, overlapped)" if world > 1 else "single GPU",
+                       "dt": args.dt, "finite": finite},
         }
+        if m.tendency_events:
+            ms = [a.elapsed_time(b) for a, b in m.tendency_events]
+            kern_ms = float(np.mean(ms))
+            achieved = TEND_BYTES_PER_CELL * cells / (kern_ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "k_tendency (fused RHS of u,v,h,A incl. Lorentz force)", "achieved": achieved,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells, "avg_launch_ms": kern_ms,
+                                "launches_timed": len(ms),
+                                "whole_step_GBps": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9}
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args, cfg, g)
+            line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -119,6 +119,53 @@ int swmhd_fill_halo_periodic_f64(double *field, int Nx, int Ny, int Hx, int Hy, 
 int swmhd_fill_halo_periodic_f32(float *field, int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
                                  int which, void *stream);
 
+int swmhd_fill_halo_periodic_multi_f64(double *const *fields, int nfields, int Nx, int Ny, int Hx, int Hy,
+                                       int64_t stride_y, int which, void *stream);
+int swmhd_fill_halo_periodic_multi_f32(float *const *fields, int nfields, int Nx, int Ny, int Hx, int Hy,
+                                       int64_t stride_y, int which, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused tendency evaluation: the whole-field form of Oceananigans' ShallowWaterModel tendency kernels
+ * (calculate_tendencies!) WITH the reference's forcing callback fused in -- one pass over the four
+ * prognostic fields produces all four tendencies; the Lorentz force never round-trips through HBM.
+ *   formulation SWMHD_VECTOR_INVARIANT: (q1,q2) = (u,v), lorentz SWMHD_LORENTZ_JACOBIAN (or NONE)
+ *       model configuration of jacobian_formulation/SWMHD_example.jl:21-33
+ *       (WENO5(vector_invariant = VelocityStencil()), mass/tracer WENO5, g, FPlane f, tracer A)
+ *   formulation SWMHD_CONSERVATIVE:     (q1,q2) = (uh,vh), lorentz SWMHD_LORENTZ_DIVERGENCE (or NONE)
+ *       model configuration of divergence_formulation/divergence_sw_mhd.jl:19-31
+ * The base right-hand side is Oceananigans' (third-party, un-vendored by the reference): it is restated from
+ * the library's published scheme, parity UNPINNED; the forcing is the reference's own.
+ * All fields need halo >= 3, filled.  Rows j_begin+1..j_end are computed.
+ * ---------------------------------------------------------------------------------------------- */
+#define SWMHD_CONSERVATIVE 0
+#define SWMHD_VECTOR_INVARIANT 1
+#define SWMHD_LORENTZ_NONE 0
+#define SWMHD_LORENTZ_JACOBIAN 1
+#define SWMHD_LORENTZ_DIVERGENCE 2
+int swmhd_tendencies_f64(const double *q1, const double *q2, const double *h, const double *A,
+                         double *G1, double *G2, double *Gh, double *GA,
+                         int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
+                         double g, double f, int formulation, int lorentz,
+                         int j_begin, int j_end, int flags, void *stream);
+int swmhd_tendencies_f32(const float *q1, const float *q2, const float *h, const float *A,
+                         float *G1, float *G2, float *Gh, float *GA,
+                         int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
+                         float g, float f, int formulation, int lorentz,
+                         int j_begin, int j_end, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RK3 substep (Oceananigans TimeSteppers rk3_substep!, `timestepper = :RungeKutta3`, SWMHD_example.jl:23):
+ *     U[f] += dt * (gamma * Gn[f] + zeta * Gm[f])    for the four prognostic fields f, interior rows only
+ * Gm == NULL selects the first-stage form  U += dt * gamma * Gn.  U, Gn, Gm are HOST arrays of 4 device
+ * pointers (parents).  (gamma, zeta) = (8/15, -), (5/12, -17/60), (3/4, -5/12).
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_rk3_substep_f64(double *const *U, const double *const *Gn, const double *const *Gm,
+                          int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                          double dt, double gamma, double zeta, int j_begin, int j_end, int flags, void *stream);
+int swmhd_rk3_substep_f32(float *const *U, const float *const *Gn, const float *const *Gm,
+                          int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
+                          float dt, float gamma, float zeta, int j_begin, int j_end, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

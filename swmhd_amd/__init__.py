@@ -7,6 +7,9 @@ from . import _lib
 from .grid import RectilinearGrid, Periodic, Bounded, Flat, Center, Face
 from .fields import Field
 from .operators import lorentz_force_func, div_lorentz
+from .model import ShallowWaterModel, VectorInvariantFormulation, ConservativeFormulation
+from .distributed import SlabDecomposition, exchange_y_halos
 
 __all__ = ["RectilinearGrid", "Periodic", "Bounded", "Flat", "Center", "Face", "Field",
-           "lorentz_force_func", "div_lorentz", "_lib"]
+           "lorentz_force_func", "div_lorentz", "ShallowWaterModel", "VectorInvariantFormulation",
+           "ConservativeFormulation", "SlabDecomposition", "exchange_y_halos", "_lib"]

@@ -11,6 +11,13 @@ STRICT = 1
 FAST = 0
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
+CONSERVATIVE, VECTOR_INVARIANT = 0, 1
+LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = 0, 1, 2
+
+
+def ptr_array(ptrs):
+    """Host array of device pointers (void*[n]) for the *_multi / rk3 entry points."""
+    return (C.c_void_p * len(ptrs))(*ptrs)
 
 
 class SwmhdError(RuntimeError):
@@ -36,13 +43,22 @@ def _declare(lib):
         f = getattr(lib, f"swmhd_fill_halo_periodic_{sfx}")
         f.argtypes = [p, i, i, i, i, i64, i, p]
         f.restype = i
+        f = getattr(lib, f"swmhd_fill_halo_periodic_multi_{sfx}")
+        f.argtypes = [C.POINTER(p), i, i, i, i, i, i64, i, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_tendencies_{sfx}")
+        f.argtypes = [p] * 8 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, i, i, i, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_rk3_substep_{sfx}")
+        f.argtypes = [C.POINTER(p), C.POINTER(p), C.POINTER(p), i, i, i, i, i64, ft, ft, ft, i, i, i, p]
+        f.restype = i
 
 
 # every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
 EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
-        "fill_halo_periodic")]
+        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "rk3_substep")]
 
 
 def lib():

@@ -30,6 +30,36 @@ template <typename T> hipError_t launch_lorentz_divergence_strict(const OpArgs<T
 
 template <typename T>
 hipError_t launch_fill_halo_periodic(T *interior, int Nx, int Ny, int Hx, int Hy, long sy, int which, hipStream_t s);
+// up to 4 fields in one launch; corners resolved by wrapping both coordinates, so x and y halos need no ordering
+template <typename T>
+hipError_t launch_fill_halo_periodic_multi(T *const *interiors, int nfields, int Nx, int Ny, int Hx, int Hy, long sy,
+                                           int which, hipStream_t s);
+
+// Arguments of the fused tendency kernels; pointers address interior cell (1,1) like OpArgs.
+template <typename T>
+struct TendArgs {
+    const T *q1, *q2, *h, *A;   // (u|uh, v|vh, h, A)
+    T *G1, *G2, *Gh, *GA;
+    int Nx, Ny, Hx, Hy;
+    long sy;
+    T dx, dy, rdx, rdy, grav, fcor;
+    int j0, j1;
+};
+template <typename T>
+struct Rk3Args {
+    T *U[4];
+    const T *Gn[4];
+    const T *Gm[4];
+    int Nx;
+    long sy;
+    int j0, j1;
+    T dt, gamma, zeta;
+    int first;
+};
+template <typename T> hipError_t launch_tendency_fast(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
+template <typename T> hipError_t launch_tendency_strict(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
+template <typename T> hipError_t launch_rk3_substep_fast(const Rk3Args<T> &a, hipStream_t s);
+template <typename T> hipError_t launch_rk3_substep_strict(const Rk3Args<T> &a, hipStream_t s);
 
 // XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin
 // over the 8 XCDs; remapping gives each XCD (and its private 4 MiB L2) a contiguous run of tiles, so the

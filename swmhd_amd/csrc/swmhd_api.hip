@@ -47,6 +47,61 @@ int halo_common(T *f, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, voi
     return hiprc(launch_fill_halo_periodic<T>(f + (long)Hy * sy + Hx, Nx, Ny, Hx, Hy, (long)sy, which, (hipStream_t)stream));
 }
 
+template <typename T>
+int halo_multi_common(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, void *stream) {
+    if (!f || nf < 1 || nf > 4 || Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if (Hx > Nx || Hy > Ny) return SWMHD_EHALO;
+    if (which & ~(SWMHD_HALO_X | SWMHD_HALO_Y)) return SWMHD_EINVAL;
+    T *p[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int k = 0; k < nf; ++k) {
+        if (!f[k]) return SWMHD_EINVAL;
+        p[k] = f[k] + (long)Hy * sy + Hx;
+    }
+    return hiprc(launch_fill_halo_periodic_multi<T>(p, nf, Nx, Ny, Hx, Hy, (long)sy, which, (hipStream_t)stream));
+}
+
+template <typename T>
+int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, T *Gh, T *GA, int Nx, int Ny, int Hx, int Hy,
+                int64_t sy, T dx, T dy, T grav, T fcor, int formulation, int lorentz, int j0, int j1, int flags, void *stream) {
+    if (!q1 || !q2 || !h || !A || !G1 || !G2 || !Gh || !GA) return SWMHD_EINVAL;
+    if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
+    if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
+    if (flags & ~SWMHD_STRICT) return SWMHD_EINVAL;
+    if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
+    // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
+    const bool ok = lorentz == SWMHD_LORENTZ_NONE || (formulation == SWMHD_VECTOR_INVARIANT && lorentz == SWMHD_LORENTZ_JACOBIAN) ||
+                    (formulation == SWMHD_CONSERVATIVE && lorentz == SWMHD_LORENTZ_DIVERGENCE);
+    if (!ok) return SWMHD_EINVAL;
+    if (Hx < 3 || Hy < 3) return SWMHD_EHALO;
+    if (j0 == j1) return SWMHD_OK;
+    TendArgs<T> a;
+    const long off = (long)Hy * sy + Hx;
+    a.q1 = q1 + off; a.q2 = q2 + off; a.h = h + off; a.A = A + off;
+    a.G1 = G1 + off; a.G2 = G2 + off; a.Gh = Gh + off; a.GA = GA + off;
+    a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
+    a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
+    hipStream_t s = (hipStream_t)stream;
+    return hiprc((flags & SWMHD_STRICT) ? launch_tendency_strict<T>(a, formulation, lorentz, s)
+                                        : launch_tendency_fast<T>(a, formulation, lorentz, s));
+}
+
+template <typename T>
+int rk3_common(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy, int64_t sy, T dt, T gamma,
+               T zeta, int j0, int j1, int flags, void *stream) {
+    if (!U || !Gn || Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if (j0 < 0 || j1 > Ny || j0 > j1 || (flags & ~SWMHD_STRICT)) return SWMHD_EINVAL;
+    Rk3Args<T> a;
+    const long off = (long)Hy * sy + Hx;
+    for (int f = 0; f < 4; ++f) {
+        if (!U[f] || !Gn[f] || (Gm && !Gm[f])) return SWMHD_EINVAL;
+        a.U[f] = U[f] + off; a.Gn[f] = Gn[f] + off; a.Gm[f] = Gm ? Gm[f] + off : Gn[f] + off;
+    }
+    a.Nx = Nx; a.sy = (long)sy; a.j0 = j0; a.j1 = j1; a.dt = dt; a.gamma = gamma; a.zeta = zeta; a.first = Gm ? 0 : 1;
+    hipStream_t s = (hipStream_t)stream;
+    return hiprc((flags & SWMHD_STRICT) ? launch_rk3_substep_strict<T>(a, s) : launch_rk3_substep_fast<T>(a, s));
+}
+
 }  // namespace
 
 extern "C" {
@@ -83,6 +138,20 @@ const char *swmhd_strerror(int rc) {
     }                                                                                                                  \
     int swmhd_fill_halo_periodic_##sfx(T *f, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, void *stream) {    \
         return halo_common<T>(f, Nx, Ny, Hx, Hy, sy, which, stream);                                                   \
+    }                                                                                                                  \
+    int swmhd_fill_halo_periodic_multi_##sfx(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy,          \
+                                             int which, void *stream) {                                                \
+        return halo_multi_common<T>(f, nf, Nx, Ny, Hx, Hy, sy, which, stream);                                         \
+    }                                                                                                                  \
+    int swmhd_tendencies_##sfx(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, T *Gh, T *GA, int Nx,   \
+                               int Ny, int Hx, int Hy, int64_t sy, T dx, T dy, T g, T f, int formulation, int lorentz, \
+                               int j0, int j1, int flags, void *stream) {                                              \
+        return tend_common<T>(q1, q2, h, A, G1, G2, Gh, GA, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz,    \
+                              j0, j1, flags, stream);                                                                  \
+    }                                                                                                                  \
+    int swmhd_rk3_substep_##sfx(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy,   \
+                                int64_t sy, T dt, T gamma, T zeta, int j0, int j1, int flags, void *stream) {          \
+        return rk3_common<T>(U, Gn, Gm, Nx, Ny, Hx, Hy, sy, dt, gamma, zeta, j0, j1, flags, stream);                   \
     }
 
 SWMHD_DEF_LORENTZ(f64, double)

@@ -1,0 +1,57 @@
+"""y-slab decomposition and ring halo exchange.
+
+The reference is single-process; periodic boundaries are Oceananigans' in-memory halo copies
+(topology = (Periodic, Periodic, Flat), jacobian_formulation/SWMHD_example.jl:16).  Here the periodic y-direction becomes a
+ring of ranks: rank r owns global rows [r*Ny/P, (r+1)*Ny/P) and all x.  Because parents are x-fastest, a block of Hy
+halo rows (full padded width, x halos included) is ONE contiguous run -> zero-copy send of the interior edge rows and
+zero-copy receive into the halo rows.  No collective other than neighbour send/recv is on the data path.
+
+One process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).  The exchange itself is device-agnostic
+torch code so that world_size-2 `gloo` tests can cover it on CPU (tests/test_distributed_cpu.py).
+"""
+import torch
+import torch.distributed as dist
+
+
+class SlabDecomposition:
+    """Pure bookkeeping: which rows does this rank own, who are its ring neighbours."""
+
+    def __init__(self, Ny_global, world_size=1, rank=0):
+        if Ny_global % world_size:
+            raise ValueError(f"Ny_global={Ny_global} not divisible by world_size={world_size}")
+        self.Ny_global, self.world_size, self.rank = Ny_global, world_size, rank
+        self.Ny_local = Ny_global // world_size
+        self.j_offset = rank * self.Ny_local
+        self.south = (rank - 1) % world_size   # owns rows below mine  (smaller j)
+        self.north = (rank + 1) % world_size   # owns rows above mine
+
+    def local_grid(self, grid_cls, Nx, x, y, halo=(3, 3), topology=("Periodic", "Periodic", "Flat")):
+        return grid_cls(size=(Nx, self.Ny_local), x=x, y=y, halo=halo, topology=topology,
+                        j_offset=self.j_offset, Ny_global=self.Ny_global)
+
+
+def exchange_y_halos(parents, Ny, Hy, decomp, group=None):
+    """Fill the south/north halo rows of every parent tensor in `parents` (shape (Ny+2Hy, W), contiguous) from the ring
+    neighbours.  x halos must already be filled (corners travel with the rows).  world_size 1: local periodic copy.
+    Returns after the exchange has been *enqueued* for CUDA/NCCL tensors (stream-ordered) or completed for CPU/gloo."""
+    if decomp.world_size == 1:
+        for p in parents:
+            p[:Hy].copy_(p[Ny:Ny + Hy])
+            p[Ny + Hy:].copy_(p[Hy:2 * Hy])
+        return
+    backend = dist.get_backend(group)
+    cuda_over_gloo = parents[0].is_cuda and backend == "gloo"   # rehearsal mode: stage the rows through the host
+    ops, stash = [], []
+    for p in parents:
+        send_s, send_n = p[Hy:2 * Hy], p[Ny:Ny + Hy]            # my southern / northern interior edge rows
+        recv_s, recv_n = p[:Hy], p[Ny + Hy:]                    # my south / north halo rows
+        if cuda_over_gloo:
+            bufs = [send_s.cpu(), send_n.cpu(), torch.empty(recv_s.shape, dtype=p.dtype), torch.empty(recv_n.shape, dtype=p.dtype)]
+            stash.append((recv_s, recv_n, bufs))
+            send_s, send_n, recv_s, recv_n = bufs
+        ops += [dist.P2POp(dist.isend, send_n, decomp.north, group), dist.P2POp(dist.irecv, recv_s, decomp.south, group),
+                dist.P2POp(dist.isend, send_s, decomp.south, group), dist.P2POp(dist.irecv, recv_n, decomp.north, group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    for recv_s, recv_n, bufs in stash:
+        recv_s.copy_(bufs[2]); recv_n.copy_(bufs[3])

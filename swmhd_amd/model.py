@@ -1,0 +1,139 @@
+"""Host-side mirror of the ShallowWaterModel configuration the reference builds, driving the HIP engine.
+
+Reference call sites being mirrored:
+    jacobian_formulation/SWMHD_example.jl:21-42     ShallowWaterModel(grid, timestepper=:RungeKutta3, WENO5 ..., g=9.81,
+        coriolis=FPlane(f=1), tracers=(:A), forcing=(u=Forcing(lorentz_force_func_x,...), v=...),
+        formulation=VectorInvariantFormulation()); set!(model, u=, v=, h=, A=); Simulation(model, dt=0.01)
+    divergence_formulation/divergence_sw_mhd.jl:19-39  same with ConservativeFormulation, forcing on uh, vh
+One `time_step(dt)` == Oceananigans' RK3 `time_step!`: 3 x {calculate_tendencies!, rk3_substep!, store_tendencies!
+(pointer swap), update_state! (halo fill)}.  All arithmetic happens in libswmhd.so; there is no CPU path.
+"""
+import torch
+
+from . import _lib
+from .distributed import SlabDecomposition, exchange_y_halos
+from .fields import Field, _SFX, _stream_ptr
+from .grid import Center, Face
+
+VectorInvariantFormulation, ConservativeFormulation = "VectorInvariant", "Conservative"
+RK3_GAMMA = (8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0)
+RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
+
+
+class ShallowWaterModel:
+    def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
+                 lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
+                 overlap=True):
+        self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
+        self.formulation = formulation
+        self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
+        if not lorentz_forcing:
+            self.lorentz_code = _lib.LORENTZ_NONE
+        else:  # the forcing that goes with each formulation in the reference
+            self.lorentz_code = _lib.LORENTZ_JACOBIAN if self.form_code == _lib.VECTOR_INVARIANT else _lib.LORENTZ_DIVERGENCE
+        self.strict = strict
+        self.decomp = decomp or SlabDecomposition(grid.Ny_global, 1, 0)
+        self.group, self.overlap = group, overlap
+        n1, n2 = ("u", "v") if self.form_code == _lib.VECTOR_INVARIANT else ("uh", "vh")
+        self.names = (n1, n2, "h", "A")
+        locs = ((Face, Center), (Center, Face), (Center, Center), (Center, Center))
+        mk = lambda loc: Field(grid, loc, dtype, device)
+        self.solution = {n: mk(l) for n, l in zip(self.names, locs)}
+        self.Gn = [mk(l) for l in locs]     # Gⁿ
+        self.Gm = [mk(l) for l in locs]     # G⁻
+        self.sfx = _SFX[dtype]
+        self.clock_time, self.iteration = 0.0, 0
+        self._comm_stream = torch.cuda.Stream() if (self.decomp.world_size > 1 and torch.cuda.is_available()) else None
+        self._L = _lib.lib()
+        self.tendency_events = None   # bench.py: list collecting (start, end) HIP events around every tendency launch
+        if any(not f.data.is_cuda for f in self.solution.values()):
+            raise _lib.SwmhdError("ShallowWaterModel runs on the GPU only (no CPU fallback)")
+
+    # --- set!(model, u=..., v=..., h=..., A=...) ---------------------------------------------------------------
+    def set(self, **kw):
+        for k, v in kw.items():
+            self.solution[k].set(v)
+        self.update_state()
+        return self
+
+    @property
+    def fields(self):
+        return [self.solution[n] for n in self.names]
+
+    # --- update_state!: fill halos (periodic x locally; y locally or by ring exchange) --------------------------
+    def _fill_x(self, stream=None):
+        g = self.grid
+        ptrs = _lib.ptr_array([f.ptr for f in self.fields])
+        which = _lib.HALO_X | (_lib.HALO_Y if self.decomp.world_size == 1 else 0)
+        f = getattr(self._L, f"swmhd_fill_halo_periodic_multi_{self.sfx}")
+        _lib.check(f(ptrs, 4, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, which, _stream_ptr(stream)), "fill_halo_multi")
+
+    def update_state(self):
+        self._fill_x()
+        if self.decomp.world_size > 1:
+            exchange_y_halos([f.data for f in self.fields], self.grid.Ny, self.grid.Hy, self.decomp, self.group)
+
+    # --- calculate_tendencies! ------------------------------------------------------------------------------
+    def calculate_tendencies(self, rows=None, stream=None):
+        if self.tendency_events is not None and rows is None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self._calculate_tendencies(rows, stream)
+            e1.record()
+            self.tendency_events.append((e0, e1))
+        else:
+            self._calculate_tendencies(rows, stream)
+
+    def _calculate_tendencies(self, rows=None, stream=None):
+        g = self.grid
+        q = self.fields
+        j0, j1 = (0, g.Ny) if rows is None else rows
+        f = getattr(self._L, f"swmhd_tendencies_{self.sfx}")
+        rc = f(q[0].ptr, q[1].ptr, q[2].ptr, q[3].ptr, self.Gn[0].ptr, self.Gn[1].ptr, self.Gn[2].ptr, self.Gn[3].ptr,
+               g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code, self.lorentz_code,
+               j0, j1, _lib.STRICT if self.strict else _lib.FAST, _stream_ptr(stream))
+        _lib.check(rc, "swmhd_tendencies")
+
+    def _substep(self, dt, stage):
+        g = self.grid
+        U = _lib.ptr_array([f.ptr for f in self.fields])
+        Gn = _lib.ptr_array([f.ptr for f in self.Gn])
+        Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
+        f = getattr(self._L, f"swmhd_rk3_substep_{self.sfx}")
+        rc = f(U, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 0, g.Ny,
+               _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
+        _lib.check(rc, "swmhd_rk3_substep")
+
+    # --- time_step!(model, dt): RungeKutta3 ------------------------------------------------------------------
+    def time_step(self, dt):
+        g, H = self.grid, self.grid.Hy
+        multi = self.decomp.world_size > 1
+        for stage in range(3):
+            if multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H and self.iteration + stage > 0:
+                # halos of x are current (filled after the previous substep); the y exchange was launched on the comm
+                # stream by the previous stage -> interior rows first, boundary strips after the exchange has landed
+                self.calculate_tendencies(rows=(H, g.Ny - H))
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                self.calculate_tendencies(rows=(0, H))
+                self.calculate_tendencies(rows=(g.Ny - H, g.Ny))
+            else:
+                self.calculate_tendencies()
+            self._substep(dt, stage)
+            self.Gn, self.Gm = self.Gm, self.Gn          # store_tendencies!: G⁻ <- Gⁿ (pointer swap, 0 bytes)
+            self._fill_x()
+            if multi:
+                if self.overlap and self._comm_stream is not None:
+                    self._comm_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._comm_stream):
+                        exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
+                else:
+                    exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
+        if multi and self.overlap and self._comm_stream is not None:
+            pass  # the last exchange is awaited by the next step's boundary strips (or by synchronize())
+        self.clock_time += dt
+        self.iteration += 1
+
+    def synchronize(self):
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        torch.cuda.synchronize()

@@ -1,0 +1,85 @@
+"""CPU, world_size 2, gloo: the y-slab decomposition + ring halo exchange reproduce the single-domain result.
+The compute on each slab is done by the ORACLE here (the product's compute is GPU-only); what is under test is the host
+logic that the multi-GPU path uses unchanged: SlabDecomposition, local grids, exchange_y_halos."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, form, lor, nsteps, out):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import oracle as O
+        from swmhd_amd import SlabDecomposition, exchange_y_halos, RectilinearGrid
+        from test_model_oracle import staggered_fields, G, F
+        N, H = 32, 3
+        q, _, dx, dy = staggered_fields(N, form)
+        q = [O.fill_halo_periodic(a, N, N, H, H) for a in q]
+        dec = SlabDecomposition(N, world, rank)
+        g = dec.local_grid(RectilinearGrid, N, x=(0, N * dx), y=(0, N * dy))
+        assert g.Ny == N // world and g.dy == dy
+        # my slab = my rows of the global parents (+ halos, to be overwritten by the exchange)
+        sl = slice(dec.j_offset, dec.j_offset + g.Ny + 2 * H)
+        loc = [np.ascontiguousarray(a[sl]) for a in q]
+        for a in loc:   # poison y halos: they must come from the neighbours
+            a[:H] = np.nan; a[g.Ny + H:] = np.nan
+        ts = [torch.from_numpy(a) for a in loc]
+        exchange_y_halos(ts, g.Ny, H, dec)
+        for a, full in zip(loc, q):
+            assert np.array_equal(a, full[sl]), "halo exchange did not reproduce the periodic global halos"
+        dt = 0.002
+        gam, zet = (8 / 15, 5 / 12, 3 / 4), (0.0, -17 / 60, -5 / 12)
+        Gm = None
+        for _ in range(nsteps):
+            for s in range(3):
+                Gn = O.tendencies(*loc, N, g.Ny, H, H, dx, dy, form, lor, G, F)
+                for a, gn, k in zip(loc, Gn, range(4)):
+                    I = (slice(H, H + g.Ny), slice(H, H + N))
+                    a[I] += dt * gam[s] * gn[I] if s == 0 else dt * (gam[s] * gn[I] + zet[s] * Gm[k][I])
+                    a[:, :H] = a[:, N:N + H]; a[:, N + H:] = a[:, H:2 * H]          # local periodic x fill
+                Gm = Gn
+                exchange_y_halos(ts, g.Ny, H, dec)
+        np.save(os.path.join(out, f"rank{rank}.npy"), np.stack([a[H:H + g.Ny] for a in loc]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+def test_two_rank_slab_run_equals_single_domain(oracle, tmp_path, form, lor):
+    from test_model_oracle import staggered_fields, G, F
+    world, nsteps = 2, 2
+    mp.spawn(_worker, args=(world, _free_port(), form, lor, nsteps, str(tmp_path)), nprocs=world, join=True)
+    N, H = 32, 3
+    q, _, dx, dy = staggered_fields(N, form)
+    q = [oracle.fill_halo_periodic(a, N, N, H, H) for a in q]
+    for _ in range(nsteps):
+        oracle.time_step(*q, N, N, H, H, dx, dy, 0.002, form, lor, G, F)
+    got = np.concatenate([np.load(tmp_path / f"rank{r}.npy") for r in range(world)], axis=1)
+    want = np.stack([a[H:H + N] for a in q])
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_decomposition_bookkeeping():
+    sys.path.insert(0, ROOT)
+    from swmhd_amd import SlabDecomposition, RectilinearGrid
+    d = SlabDecomposition(4096, 8, 3)
+    assert (d.Ny_local, d.j_offset, d.south, d.north) == (512, 1536, 2, 4)
+    assert SlabDecomposition(64, 4, 0).south == 3 and SlabDecomposition(64, 4, 3).north == 0
+    with pytest.raises(ValueError):
+        SlabDecomposition(100, 8, 0)
+    g = d.local_grid(RectilinearGrid, 4096, x=(-1, 1), y=(-10, 10))
+    assert g.Ny == 512 and g.dy == 20 / 4096 and abs(g.yc[3] - (-10 + (1536 + 0.5) * g.dy)) < 1e-12

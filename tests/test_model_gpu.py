@@ -1,0 +1,155 @@
+"""GPU parity tests of the fused tendency engine (HIP, through the C-ABI) against the CPU oracle.
+
+Bars: SWMHD_STRICT bit-identical to the oracle (which for the base RHS is a PARITY-UNPINNED restatement of Oceananigans'
+scheme, and for the forcing restates the reference's own code); fast path max|dG| <= 1e-12 * max|G| (fp64) per RHS
+evaluation, <= 1e-4 * max|G| (fp32: WENO smoothness weights amplify fp32 rounding)."""
+import numpy as np
+import pytest
+import torch
+
+import helpers as Hh
+from test_model_oracle import staggered_fields, G, F
+
+pytestmark = pytest.mark.gpu
+CASES = [(1, 1), (1, 0), (0, 2), (0, 0)]   # (formulation, lorentz)
+FORM = {0: "Conservative", 1: "VectorInvariant"}
+
+
+def random_state(Nx, Ny, H, seed, form, dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    shp = (Ny + 2 * H, Nx + 2 * H)
+    h = 1.0 + 0.3 * rng.random(shp)
+    u, v = 0.5 * rng.standard_normal(shp), 0.5 * rng.standard_normal(shp)
+    A = rng.standard_normal(shp)
+    q1, q2 = (u, v) if form == 1 else (h * u, h * v)
+    return [np.ascontiguousarray(Hh.fill_halo_periodic(a, Nx, Ny, H, H).astype(dtype)) for a in (q1, q2, h, A)]
+
+
+def make_model(S, Nx, Ny, form, lor, q, dx, dy, strict, dtype=torch.float64):
+    g = S.RectilinearGrid(size=(Nx, Ny), x=(0, dx * Nx), y=(0, dy * Ny), halo=(3, 3))
+    m = S.ShallowWaterModel(g, G, F, formulation=FORM[form], lorentz_forcing=bool(lor), dtype=dtype, strict=strict)
+    for f, a in zip(m.fields, q):
+        f.data.copy_(torch.from_numpy(a))
+    return m
+
+
+@pytest.mark.parametrize("form,lor", CASES)
+@pytest.mark.parametrize("shape", [(64, 8), (100, 37), (7, 5), (130, 70), (256, 64)])
+def test_tendencies_strict_bitwise_fast_within_tolerance(swmhd, oracle, form, lor, shape):
+    Nx, Ny = shape
+    q = random_state(Nx, Ny, 3, 7 + Nx, form)
+    dx, dy = 0.11, 0.13
+    want = oracle.tendencies(*q, Nx, Ny, 3, 3, dx, dy, form, lor, G, F, nthreads=8)
+    m = make_model(swmhd, Nx, Ny, form, lor, q, dx, dy, strict=True)
+    m.calculate_tendencies(); torch.cuda.synchronize()
+    I = m.grid.interior
+    for w, gf in zip(want, m.Gn):
+        got = gf.numpy()
+        assert np.array_equal(w[I], got[I]), f"strict differs: max {np.abs(w[I] - got[I]).max()} of {np.abs(w[I]).max()}"
+    m2 = make_model(swmhd, Nx, Ny, form, lor, q, dx, dy, strict=False)
+    m2.calculate_tendencies(); torch.cuda.synchronize()
+    for w, gf in zip(want, m2.Gn):
+        assert np.abs(w[I] - gf.numpy()[I]).max() <= 1e-12 * np.abs(w[I]).max()
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+def test_smooth_fields_and_pde_convergence_on_gpu(swmhd, form, lor):
+    """The HIP engine itself converges to the continuous equations (no oracle involved)."""
+    from test_model_oracle import pde_rhs, Lx, Ly
+    errs = []
+    for N in (64, 128):
+        q, (cc, fc, cf), dx, dy = staggered_fields(N, form)
+        m = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=False)
+        m.calculate_tendencies(); torch.cuda.synchronize()
+        I = m.grid.interior
+        r1 = pde_rhs(fc[0][I], fc[1][I], form, lor)[0]
+        rc = pde_rhs(cc[0][I], cc[1][I], form, lor)
+        errs.append([np.abs(m.Gn[0].numpy()[I] - r1).max() / np.abs(r1).max(), np.abs(m.Gn[3].numpy()[I] - rc[3]).max() / np.abs(rc[3]).max()])
+    E = np.array(errs)
+    assert np.all(np.log2(E[0] / E[1]) > 1.9)
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+def test_fp32_tendencies(swmhd, oracle, form, lor):
+    N = 96
+    q, _, dx, dy = staggered_fields(N, form)
+    q32 = [a.astype(np.float32) for a in q]
+    want = oracle.tendencies(*q32, N, N, 3, 3, dx, dy, form, lor, G, F, nthreads=8)
+    ref64 = oracle.tendencies(*q, N, N, 3, 3, dx, dy, form, lor, G, F, nthreads=8)
+    m = make_model(swmhd, N, N, form, lor, q32, dx, dy, strict=True, dtype=torch.float32)
+    m.calculate_tendencies(); torch.cuda.synchronize()
+    I = m.grid.interior
+    for w, gf in zip(want, m.Gn):
+        assert np.array_equal(w[I], gf.numpy()[I])
+    m2 = make_model(swmhd, N, N, form, lor, q32, dx, dy, strict=False, dtype=torch.float32)
+    m2.calculate_tendencies(); torch.cuda.synchronize()
+    for w, gf in zip(ref64, m2.Gn):
+        assert np.abs(w[I] - gf.numpy()[I]).max() <= 1e-4 * np.abs(w[I]).max()
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+def test_row_ranges_compose(swmhd, form, lor):
+    """Interior rows + two boundary strips (the overlap split of SURVEY.md 8(e)) == one full launch, bitwise."""
+    Nx, Ny = 90, 40
+    q = random_state(Nx, Ny, 3, 3, form)
+    m = make_model(swmhd, Nx, Ny, form, lor, q, 0.1, 0.1, strict=False)
+    m.calculate_tendencies(); torch.cuda.synchronize()
+    full = [g_.data.clone() for g_ in m.Gn]
+    for g_ in m.Gn:
+        g_.data.fill_(-1.5)
+    m.calculate_tendencies(rows=(3, Ny - 3)); m.calculate_tendencies(rows=(0, 3)); m.calculate_tendencies(rows=(Ny - 3, Ny))
+    torch.cuda.synchronize()
+    I = m.grid.interior
+    for a, b in zip(full, m.Gn):
+        assert torch.equal(a[I], b.data[I])
+        halo = b.data.clone(); halo[I] = -1.5
+        assert torch.all(halo == -1.5)
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+def test_time_steps_match_oracle(swmhd, oracle, form, lor):
+    """Three full RK3 steps (9 tendency evaluations, 9 substeps, 9 halo fills): strict bitwise vs the oracle's time_step."""
+    N = 48
+    q, _, dx, dy = staggered_fields(N, form)
+    q = [oracle.fill_halo_periodic(a, N, N, 3, 3) for a in q]
+    m = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=True)
+    mf = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=False)
+    dt = 0.002
+    qo = [a.copy() for a in q]
+    for _ in range(3):
+        oracle.time_step(*qo, N, N, 3, 3, dx, dy, dt, form, lor, G, F, nthreads=8)
+        m.time_step(dt); mf.time_step(dt)
+    m.synchronize()
+    for w, f in zip(qo, m.fields):
+        assert np.array_equal(w, f.numpy()), "strict time stepping (incl. halos) differs from the oracle"
+    for w, f in zip(qo, mf.fields):
+        assert np.abs(w - f.numpy()).max() <= 1e-12 * np.abs(w).max()
+    assert m.iteration == 3 and abs(m.clock_time - 3 * dt) < 1e-15
+
+
+def test_halo_multi_matches_numpy(swmhd):
+    Nx, Ny, H = 33, 17, 3
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, 1), y=(0, 1), halo=(H, H))
+    m = swmhd.ShallowWaterModel(g)
+    rng = np.random.default_rng(5)
+    raw = [rng.standard_normal(g.parent_shape) for _ in range(4)]
+    for f, a in zip(m.fields, raw):
+        f.data.copy_(torch.from_numpy(a))
+    m.update_state(); torch.cuda.synchronize()
+    for f, a in zip(m.fields, raw):
+        assert np.array_equal(f.numpy(), Hh.fill_halo_periodic(a, Nx, Ny, H, H))
+
+
+def test_model_rejects_bad_arguments(swmhd):
+    L = swmhd._lib.lib()
+    g = swmhd.RectilinearGrid(size=(16, 16), x=(0, 1), y=(0, 1), halo=(3, 3))
+    m = swmhd.ShallowWaterModel(g)
+    q = m.fields
+    f = L.swmhd_tendencies_f64
+    args = lambda form, lor, H: (q[0].ptr, q[1].ptr, q[2].ptr, q[3].ptr, m.Gn[0].ptr, m.Gn[1].ptr, m.Gn[2].ptr, m.Gn[3].ptr,
+                                 16, 16, H, H, q[0].stride_y, 0.1, 0.1, 9.81, 1.0, form, lor, 0, 16, 0, None)
+    assert f(*args(0, 1, 3)) == 1      # Jacobian forcing with the conservative formulation
+    assert f(*args(1, 2, 3)) == 1      # divergence forcing with the vector-invariant formulation
+    assert f(*args(1, 1, 2)) == 2      # halo 2 < 3
+    assert f(*args(1, 1, 3)) == 0
+    torch.cuda.synchronize()
