@@ -166,6 +166,27 @@ int swmhd_rk3_substep_f32(float *const *U, const float *const *Gn, const float *
                           int Nx, int Ny, int Hx, int Hy, int64_t stride_y,
                           float dt, float gamma, float zeta, int j_begin, int j_end, int flags, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused RK3 stage = calculate_tendencies! + rk3_substep! in ONE pass (the old state of a cell is already on chip
+ * when its tendency is known):
+ *     Gn[f]   = tendency of field f evaluated from q[0..3]                     (written iff store_G != 0)
+ *     qnew[f] = q[f] + dt * (gamma * Gn[f] + zeta * Gm[f])                     (Gm == NULL: first-stage form)
+ * q, qnew, Gn, Gm are HOST arrays of 4 device pointers (parents) in the order (u|uh, v|vh, h, A).  qnew must not
+ * alias q: neighbouring workgroups still read the old state through their halos (ping-pong the two sets).
+ * Only the interior of qnew is written; fill its halos before the next stage.  The last stage of a step may pass
+ * store_G = 0 (the next step's first stage has zeta = 0 and never reads it).
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_tendencies_rk3_f64(const double *const *q, double *const *qnew, double *const *Gn, const double *const *Gm,
+                             int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
+                             double g, double f, int formulation, int lorentz,
+                             double dt, double gamma, double zeta, int store_G,
+                             int j_begin, int j_end, int flags, void *stream);
+int swmhd_tendencies_rk3_f32(const float *const *q, float *const *qnew, float *const *Gn, const float *const *Gm,
+                             int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
+                             float g, float f, int formulation, int lorentz,
+                             float dt, float gamma, float zeta, int store_G,
+                             int j_begin, int j_end, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

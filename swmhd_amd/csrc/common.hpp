@@ -44,6 +44,12 @@ struct TendArgs {
     long sy;
     T dx, dy, rdx, rdy, grav, fcor;
     int j0, j1;
+    // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
+    // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
+    int fuse, first, store_G;
+    T *Unew[4];
+    const T *Gm[4];
+    T dt, gamma, zeta;
 };
 template <typename T>
 struct Rk3Args {

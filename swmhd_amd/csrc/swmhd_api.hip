@@ -61,8 +61,17 @@ int halo_multi_common(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64
 }
 
 template <typename T>
+struct FuseRk3 {
+    T *Unew[4];
+    const T *const *Gm;
+    T dt, gamma, zeta;
+    int store_G;
+};
+
+template <typename T>
 int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, T *Gh, T *GA, int Nx, int Ny, int Hx, int Hy,
-                int64_t sy, T dx, T dy, T grav, T fcor, int formulation, int lorentz, int j0, int j1, int flags, void *stream) {
+                int64_t sy, T dx, T dy, T grav, T fcor, int formulation, int lorentz, int j0, int j1, int flags, void *stream,
+                const FuseRk3<T> *rk = nullptr) {
     if (!q1 || !q2 || !h || !A || !G1 || !G2 || !Gh || !GA) return SWMHD_EINVAL;
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
@@ -81,9 +90,30 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.G1 = G1 + off; a.G2 = G2 + off; a.Gh = Gh + off; a.GA = GA + off;
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
+    a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
+    for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
+    if (rk) {
+        a.fuse = 1; a.first = rk->Gm ? 0 : 1; a.store_G = rk->store_G; a.dt = rk->dt; a.gamma = rk->gamma; a.zeta = rk->zeta;
+        for (int f = 0; f < 4; ++f) { a.Unew[f] = rk->Unew[f] + off; a.Gm[f] = rk->Gm ? rk->Gm[f] + off : nullptr; }
+    }
     hipStream_t s = (hipStream_t)stream;
     return hiprc((flags & SWMHD_STRICT) ? launch_tendency_strict<T>(a, formulation, lorentz, s)
                                         : launch_tendency_fast<T>(a, formulation, lorentz, s));
+}
+
+template <typename T>
+int tend_rk3_common(const T *const *q, T *const *qnew, T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy, int64_t sy,
+                    T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, T gamma, T zeta, int store_G, int j0, int j1,
+                    int flags, void *stream) {
+    if (!q || !qnew || !Gn) return SWMHD_EINVAL;
+    for (int f = 0; f < 4; ++f) {
+        if (!q[f] || !qnew[f] || !Gn[f] || (Gm && !Gm[f])) return SWMHD_EINVAL;
+        for (int k = 0; k < 4; ++k)
+            if (qnew[f] == q[k]) return SWMHD_EINVAL;   // the new state must not alias the state being read through halos
+    }
+    FuseRk3<T> rk{{qnew[0], qnew[1], qnew[2], qnew[3]}, Gm, dt, gamma, zeta, store_G ? 1 : 0};
+    return tend_common<T>(q[0], q[1], q[2], q[3], Gn[0], Gn[1], Gn[2], Gn[3], Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation,
+                          lorentz, j0, j1, flags, stream, &rk);
 }
 
 template <typename T>
@@ -148,6 +178,12 @@ const char *swmhd_strerror(int rc) {
                                int j0, int j1, int flags, void *stream) {                                              \
         return tend_common<T>(q1, q2, h, A, G1, G2, Gh, GA, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz,    \
                               j0, j1, flags, stream);                                                                  \
+    }                                                                                                                  \
+    int swmhd_tendencies_rk3_##sfx(const T *const *q, T *const *qnew, T *const *Gn, const T *const *Gm, int Nx, int Ny, \
+                                   int Hx, int Hy, int64_t sy, T dx, T dy, T g, T f, int formulation, int lorentz, T dt, \
+                                   T gamma, T zeta, int store_G, int j0, int j1, int flags, void *stream) {              \
+        return tend_rk3_common<T>(q, qnew, Gn, Gm, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz, dt, gamma,   \
+                                  zeta, store_G, j0, j1, flags, stream);                                                \
     }                                                                                                                  \
     int swmhd_rk3_substep_##sfx(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy,   \
                                 int64_t sy, T dt, T gamma, T zeta, int j0, int j1, int flags, void *stream) {          \

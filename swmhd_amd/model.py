@@ -23,7 +23,7 @@ RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True):
+                 overlap=True, fused=True):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -39,6 +39,8 @@ class ShallowWaterModel:
         locs = ((Face, Center), (Center, Face), (Center, Center), (Center, Center))
         mk = lambda loc: Field(grid, loc, dtype, device)
         self.solution = {n: mk(l) for n, l in zip(self.names, locs)}
+        self.fused = fused                    # one kernel per RK3 stage (tendencies + substep), state ping-ponged
+        self._alt = {n: mk(l) for n, l in zip(self.names, locs)} if fused else None
         self.Gn = [mk(l) for l in locs]     # Gⁿ
         self.Gm = [mk(l) for l in locs]     # G⁻
         self.sfx = _SFX[dtype]
@@ -104,32 +106,58 @@ class ShallowWaterModel:
                _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
         _lib.check(rc, "swmhd_rk3_substep")
 
+    def _stage_fused(self, dt, stage, rows=None):
+        """calculate_tendencies! + rk3_substep! in one launch: reads the current state, writes the new state into the
+        alternate buffers (swmhd_tendencies_rk3_*)."""
+        g = self.grid
+        j0, j1 = (0, g.Ny) if rows is None else rows
+        q = _lib.ptr_array([f.ptr for f in self.fields])
+        qn = _lib.ptr_array([self._alt[n].ptr for n in self.names])
+        Gn = _lib.ptr_array([f.ptr for f in self.Gn])
+        Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
+        f = getattr(self._L, f"swmhd_tendencies_rk3_{self.sfx}")
+        timed = self.tendency_events is not None and rows is None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
+               self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
+               _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
+        if timed:
+            e1.record()
+            self.tendency_events.append((e0, e1))
+        _lib.check(rc, "swmhd_tendencies_rk3")
+
     # --- time_step!(model, dt): RungeKutta3 ------------------------------------------------------------------
     def time_step(self, dt):
         g, H = self.grid, self.grid.Hy
         multi = self.decomp.world_size > 1
+        overlap = multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H
         for stage in range(3):
-            if multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H and self.iteration + stage > 0:
-                # halos of x are current (filled after the previous substep); the y exchange was launched on the comm
-                # stream by the previous stage -> interior rows first, boundary strips after the exchange has landed
-                self.calculate_tendencies(rows=(H, g.Ny - H))
+            # one RK3 stage over a row range: either the fused kernel or tendencies followed (later) by the substep
+            run = (lambda rows=None: self._stage_fused(dt, stage, rows)) if self.fused else (lambda rows=None: self.calculate_tendencies(rows=rows))
+            if overlap and self.iteration + stage > 0:
+                # x halos are current; the y exchange of the previous stage is in flight on the comm stream ->
+                # interior rows first, the two boundary strips after the exchange has landed (SURVEY.md 8(e))
+                run((H, g.Ny - H))
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
-                self.calculate_tendencies(rows=(0, H))
-                self.calculate_tendencies(rows=(g.Ny - H, g.Ny))
+                run((0, H))
+                run((g.Ny - H, g.Ny))
             else:
-                self.calculate_tendencies()
-            self._substep(dt, stage)
+                run()
+            if self.fused:
+                self.solution, self._alt = self._alt, self.solution      # the new state becomes current
+            else:
+                self._substep(dt, stage)
             self.Gn, self.Gm = self.Gm, self.Gn          # store_tendencies!: G⁻ <- Gⁿ (pointer swap, 0 bytes)
             self._fill_x()
             if multi:
-                if self.overlap and self._comm_stream is not None:
+                if overlap:
                     self._comm_stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._comm_stream):
                         exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
                 else:
                     exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
-        if multi and self.overlap and self._comm_stream is not None:
-            pass  # the last exchange is awaited by the next step's boundary strips (or by synchronize())
         self.clock_time += dt
         self.iteration += 1
 

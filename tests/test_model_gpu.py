@@ -25,9 +25,9 @@ def random_state(Nx, Ny, H, seed, form, dtype=np.float64):
     return [np.ascontiguousarray(Hh.fill_halo_periodic(a, Nx, Ny, H, H).astype(dtype)) for a in (q1, q2, h, A)]
 
 
-def make_model(S, Nx, Ny, form, lor, q, dx, dy, strict, dtype=torch.float64):
+def make_model(S, Nx, Ny, form, lor, q, dx, dy, strict, dtype=torch.float64, fused=True):
     g = S.RectilinearGrid(size=(Nx, Ny), x=(0, dx * Nx), y=(0, dy * Ny), halo=(3, 3))
-    m = S.ShallowWaterModel(g, G, F, formulation=FORM[form], lorentz_forcing=bool(lor), dtype=dtype, strict=strict)
+    m = S.ShallowWaterModel(g, G, F, formulation=FORM[form], lorentz_forcing=bool(lor), dtype=dtype, strict=strict, fused=fused)
     for f, a in zip(m.fields, q):
         f.data.copy_(torch.from_numpy(a))
     return m
@@ -106,14 +106,16 @@ def test_row_ranges_compose(swmhd, form, lor):
         assert torch.all(halo == -1.5)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
-def test_time_steps_match_oracle(swmhd, oracle, form, lor):
-    """Three full RK3 steps (9 tendency evaluations, 9 substeps, 9 halo fills): strict bitwise vs the oracle's time_step."""
+def test_time_steps_match_oracle(swmhd, oracle, form, lor, fused):
+    """Three full RK3 steps (9 tendency evaluations, 9 substeps, 9 halo fills): strict bitwise vs the oracle's time_step,
+    for the fused one-kernel-per-stage path (ping-ponged state) and for the separate tendencies + rk3_substep path."""
     N = 48
     q, _, dx, dy = staggered_fields(N, form)
     q = [oracle.fill_halo_periodic(a, N, N, 3, 3) for a in q]
-    m = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=True)
-    mf = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=False)
+    m = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=True, fused=fused)
+    mf = make_model(swmhd, N, N, form, lor, q, dx, dy, strict=False, fused=fused)
     dt = 0.002
     qo = [a.copy() for a in q]
     for _ in range(3):
