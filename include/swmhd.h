@@ -46,6 +46,7 @@ extern "C" {
 /* flags */
 #define SWMHD_FAST 0
 #define SWMHD_STRICT 1
+#define SWMHD_TILE_KERNEL 2   /* tendency entry points only: use the LDS-tiled kernel instead of the row-marching one (A/B) */
 
 /* topology codes (Oceananigans.Grids.topology) */
 #define SWMHD_PERIODIC 0

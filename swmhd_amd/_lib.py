@@ -9,6 +9,7 @@ _LIB = None
 
 STRICT = 1
 FAST = 0
+TILE_KERNEL = 2
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
 CONSERVATIVE, VECTOR_INVARIANT = 0, 1

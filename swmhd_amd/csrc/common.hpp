@@ -47,6 +47,7 @@ struct TendArgs {
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
+    int kernel_variant;   // 0 = default (row-marching where available), 1 = LDS-tiled kernel (A/B measurements, strict builds)
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;

@@ -23,7 +23,7 @@ RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True, fused=True):
+                 overlap=True, fused=True, tile_kernel=False):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -32,6 +32,7 @@ class ShallowWaterModel:
         else:  # the forcing that goes with each formulation in the reference
             self.lorentz_code = _lib.LORENTZ_JACOBIAN if self.form_code == _lib.VECTOR_INVARIANT else _lib.LORENTZ_DIVERGENCE
         self.strict = strict
+        self._flags = (_lib.STRICT if strict else _lib.FAST) | (_lib.TILE_KERNEL if tile_kernel else 0)
         self.decomp = decomp or SlabDecomposition(grid.Ny_global, 1, 0)
         self.group, self.overlap = group, overlap
         n1, n2 = ("u", "v") if self.form_code == _lib.VECTOR_INVARIANT else ("uh", "vh")
@@ -93,7 +94,7 @@ class ShallowWaterModel:
         f = getattr(self._L, f"swmhd_tendencies_{self.sfx}")
         rc = f(q[0].ptr, q[1].ptr, q[2].ptr, q[3].ptr, self.Gn[0].ptr, self.Gn[1].ptr, self.Gn[2].ptr, self.Gn[3].ptr,
                g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code, self.lorentz_code,
-               j0, j1, _lib.STRICT if self.strict else _lib.FAST, _stream_ptr(stream))
+               j0, j1, self._flags, _stream_ptr(stream))
         _lib.check(rc, "swmhd_tendencies")
 
     def _substep(self, dt, stage):
@@ -122,7 +123,7 @@ class ShallowWaterModel:
             e0.record()
         rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
                self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
-               _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
+               self._flags, _stream_ptr())
         if timed:
             e1.record()
             self.tendency_events.append((e0, e1))
