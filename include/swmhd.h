@@ -46,7 +46,7 @@ extern "C" {
 /* flags */
 #define SWMHD_FAST 0
 #define SWMHD_STRICT 1
-#define SWMHD_TILE_KERNEL 2   /* tendency entry points only: use the LDS-tiled kernel instead of the row-marching one (A/B) */
+#define SWMHD_TILE_KERNEL 2   /* use the LDS-tiled kernel instead of the row-marching one (A/B measurements) */
 
 /* topology codes (Oceananigans.Grids.topology) */
 #define SWMHD_PERIODIC 0

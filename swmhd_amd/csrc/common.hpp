@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace swmhd {
 
@@ -19,6 +20,7 @@ struct OpArgs {
     T dx, dy, rdx, rdy;
     int j0, j1;  // rows [j0, j1) are computed (0-based)
     int topo_x, topo_y;
+    int kernel_variant;  // 0 = default (row-marching in fast builds), 1 = LDS-tiled kernel
 };
 
 // launchers, one pair per translation unit (fast: reciprocal multiplies + FMA; strict: reference op order,

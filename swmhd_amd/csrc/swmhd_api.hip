@@ -23,9 +23,10 @@ int lorentz_common(bool divergence, const T *A, const T *h, T *Fx, T *Fy, int Nx
             return SWMHD_EINVAL;
         return SWMHD_ENOTSUP;  // Bounded wall branches: SURVEY.md 8(f) rank 3
     }
-    if (flags & ~SWMHD_STRICT) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL)) return SWMHD_EINVAL;
     if (j_begin == j_end) return SWMHD_OK;
     OpArgs<T> a;
+    a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : 0;
     const long off = (long)Hy * sy + Hx;
     a.A = A + off; a.h = h + off; a.Fx = Fx + off; a.Fy = Fy + off;
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;

@@ -38,7 +38,7 @@ def _oracle(O, form, A, h, g):
     return fn(A, h, g.Nx, g.Ny, g.Hx, g.Hy, g.dx, g.dy, nthreads=8)
 
 
-SHAPES = [(64, 16), (100, 37), (5, 4), (130, 70), (256, 256), (513, 33), (1, 1)]
+SHAPES = [(64, 16), (100, 37), (5, 4), (130, 70), (256, 256), (513, 33), (1, 1), (252, 40), (253, 3), (700, 129)]
 
 
 @pytest.mark.parametrize("form", ["jacobian", "divergence"])
@@ -57,9 +57,10 @@ def test_strict_is_bitwise_and_fast_within_tolerance(swmhd, oracle, form, dtype,
     I = g.interior
     for w, q in zip(want, got):
         assert np.array_equal(w[I], q[I]), f"strict {form} differs from oracle: max {np.abs(w[I]-q[I]).max()}"
-    fast = _run(swmhd, form, g, f, strict=False)
-    for w, q in zip(want, fast):
-        assert np.abs(w[I] - q[I]).max() <= TOL[dtype] * max(np.abs(w[I]).max(), 1e-300)
+    for tile in (False, True):   # default fast path = row-marching kernel; tile_kernel=True = LDS-tiled fast kernel
+        fast = _run(swmhd, form, g, f, strict=False, tile_kernel=tile)
+        for w, q in zip(want, fast):
+            assert np.abs(w[I] - q[I]).max() <= TOL[dtype] * max(np.abs(w[I]).max(), 1e-300), ("tile" if tile else "march")
 
 
 @pytest.mark.parametrize("form", ["jacobian", "divergence"])
