@@ -188,6 +188,26 @@ int swmhd_tendencies_rk3_f32(const float *const *q, float *const *qnew, float *c
                              float dt, float gamma, float zeta, int store_G,
                              int j_begin, int j_end, int flags, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Energy and extrema diagnostics, one pass (the reference computes them every iteration:
+ * kinetic/magnetic/potential_energy_func SWMHD_example.jl:67-77 / divergence_sw_mhd.jl:63-74 written by the
+ * NetCDFOutputWriter :87-92, and max|u|, max|A|, min h in the progress callback :47-65).
+ *   out[0..6] = { KE, ME, PE, max|u|, max|v|, max|A|, min h }  over rows j_begin+1..j_end of this (slab of the) domain,
+ *   energies already multiplied by dx*dy (sum over ranks = the reference's mean(...)*Lx*Ly); always double.
+ * `out` (7 doubles) and `workspace` (SWMHD_DIAG_WORKSPACE doubles) are DEVICE buffers; deterministic summation order.
+ * Needs halo >= 1, filled.  For formulation SWMHD_CONSERVATIVE velocities are uh/ℑxᶠh, vh/ℑyᶠh.
+ * ---------------------------------------------------------------------------------------------- */
+#define SWMHD_DIAG_NOUT 7
+#define SWMHD_DIAG_WORKSPACE (1024 * 7)
+int swmhd_diagnostics_f64(const double *q1, const double *q2, const double *h, const double *A,
+                          int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
+                          double g, double h_ref, int formulation, int j_begin, int j_end,
+                          double *workspace, double *out, void *stream);
+int swmhd_diagnostics_f32(const float *q1, const float *q2, const float *h, const float *A,
+                          int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
+                          float g, float h_ref, int formulation, int j_begin, int j_end,
+                          double *workspace, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

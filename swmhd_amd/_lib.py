@@ -12,6 +12,7 @@ FAST = 0
 TILE_KERNEL = 2
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
+DIAG_NOUT, DIAG_WORKSPACE = 7, 1024 * 7
 CONSERVATIVE, VECTOR_INVARIANT = 0, 1
 LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = 0, 1, 2
 
@@ -53,6 +54,9 @@ def _declare(lib):
         f = getattr(lib, f"swmhd_tendencies_rk3_{sfx}")
         f.argtypes = [C.POINTER(p)] * 4 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, ft, ft, ft, i, i, i, i, p]
         f.restype = i
+        f = getattr(lib, f"swmhd_diagnostics_{sfx}")
+        f.argtypes = [p, p, p, p, i, i, i, i, i64, ft, ft, ft, ft, i, i, i, p, p, p]
+        f.restype = i
         f = getattr(lib, f"swmhd_rk3_substep_{sfx}")
         f.argtypes = [C.POINTER(p), C.POINTER(p), C.POINTER(p), i, i, i, i, i64, ft, ft, ft, i, i, i, p]
         f.restype = i
@@ -62,7 +66,7 @@ def _declare(lib):
 EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
-        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep")]
+        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "diagnostics")]
 
 
 def lib():

@@ -71,6 +71,11 @@ template <typename T> hipError_t launch_tendency_strict(const TendArgs<T> &a, in
 template <typename T> hipError_t launch_rk3_substep_fast(const Rk3Args<T> &a, hipStream_t s);
 template <typename T> hipError_t launch_rk3_substep_strict(const Rk3Args<T> &a, hipStream_t s);
 
+// energies + extrema; workspace >= SWMHD_DIAG_WORKSPACE doubles, out = 7 doubles (both device memory)
+template <typename T>
+hipError_t launch_diagnostics(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int j0, int j1, long sy, T dx, T dy,
+                              T grav, T href, int form, double *workspace, double *out, hipStream_t s);
+
 // XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin
 // over the 8 XCDs; remapping gives each XCD (and its private 4 MiB L2) a contiguous run of tiles, so the
 // halo rows/columns that y-/x-adjacent tiles share are L2 hits instead of second HBM/MALL fetches.

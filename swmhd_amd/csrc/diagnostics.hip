@@ -1,0 +1,114 @@
+// Energy and extrema diagnostics in one pass over the prognostic fields.
+//
+// The reference evaluates these every iteration through Oceananigans AbstractOperations + NetCDFOutputWriter:
+//   kinetic/magnetic/potential/total_energy_func   jacobian_formulation/SWMHD_example.jl:67-77, :87-92
+//                                                  divergence_formulation/divergence_sw_mhd.jl:63-74, :85-91
+//   progress callback max|u|, max|A|, min h        SWMHD_example.jl:47-65
+// Definitions used here (cell-centred, 2nd order; the exact interpolation placement inside Oceananigans' AbstractOperations
+// is library-internal and unpinned -- the committed energy plots are reproduced to plot accuracy, tests/test_diagnostics*):
+//   KE = sum_ij 1/2 h (ℑxᶜ(u²) + ℑyᶜ(v²)) dx dy          (conservative: u = uh/ℑxᶠh, v = vh/ℑyᶠh)
+//   ME = sum_ij 1/2 (ℑxᶜ((∂xA)²/ℑxᶠh) + ℑyᶜ((∂yA)²/ℑyᶠh)) dx dy     [= 1/2 h |B|², B = ẑ×∇A / h]
+//   PE = sum_ij 1/2 g (h − h_ref)² dx dy
+//   max|u|, max|v|, max|A|, min h over the interior
+// Two deterministic stages: per-workgroup partials (fixed grid), then one workgroup folds them in index order.
+#include "common.hpp"
+
+namespace swmhd {
+namespace {
+
+constexpr int NB = 1024, NT = 256, NQ = 7;
+
+template <typename T>
+struct DiagArgs {
+    const T *q1, *q2, *h, *A;
+    int Nx, Ny, j0, j1;
+    long sy;
+    T dx, dy, grav, href;
+    int form;
+    double *part;   // [NB][NQ]
+    double *out;    // [NQ]
+};
+
+__device__ __forceinline__ void fold(double *acc, const double *v) {
+    acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2];
+    acc[3] = fmax(acc[3], v[3]); acc[4] = fmax(acc[4], v[4]); acc[5] = fmax(acc[5], v[5]); acc[6] = fmin(acc[6], v[6]);
+}
+
+__device__ void block_reduce(double *acc, double (*sm)[NQ]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) sm[t][q] = acc[q];
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            double a[NQ], b[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { a[q] = sm[t][q]; b[q] = sm[t + s][q]; }
+            fold(a, b);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) sm[t][q] = a[q];
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void k_diag_partial(DiagArgs<T> a) {
+    __shared__ double sm[NT][NQ];
+    double acc[NQ] = {0, 0, 0, 0, 0, 0, 1e300};
+    const double rdx = 1.0 / (double)a.dx, rdy = 1.0 / (double)a.dy;
+    const long ncell = (long)a.Nx * (a.j1 - a.j0);
+    for (long e = (long)blockIdx.x * NT + threadIdx.x; e < ncell; e += (long)NB * NT) {
+        const int y = a.j0 + (int)(e / a.Nx), x = (int)(e % a.Nx);
+        const long o = (long)y * a.sy + x;
+        auto Q1 = [&](int di, int dj) -> double { return (double)a.q1[o + dj * a.sy + di]; };
+        auto Q2 = [&](int di, int dj) -> double { return (double)a.q2[o + dj * a.sy + di]; };
+        auto H = [&](int di, int dj) -> double { return (double)a.h[o + dj * a.sy + di]; };
+        auto AA = [&](int di, int dj) -> double { return (double)a.A[o + dj * a.sy + di]; };
+        const double hc = H(0, 0);
+        const double hw = 0.5 * (H(-1, 0) + hc), he = 0.5 * (hc + H(1, 0)), hs = 0.5 * (H(0, -1) + hc), hn = 0.5 * (hc + H(0, 1));
+        double uw = Q1(0, 0), ue = Q1(1, 0), vs = Q2(0, 0), vn = Q2(0, 1);
+        if (a.form == 0) { uw /= hw; ue /= he; vs /= hs; vn /= hn; }   // velocities from transports
+        const double ke = 0.5 * hc * (0.5 * (uw * uw + ue * ue) + 0.5 * (vs * vs + vn * vn));
+        const double axw = (AA(0, 0) - AA(-1, 0)) * rdx, axe = (AA(1, 0) - AA(0, 0)) * rdx;
+        const double ays = (AA(0, 0) - AA(0, -1)) * rdy, ayn = (AA(0, 1) - AA(0, 0)) * rdy;
+        const double me = 0.5 * (0.5 * (axw * axw / hw + axe * axe / he) + 0.5 * (ays * ays / hs + ayn * ayn / hn));
+        const double dh = hc - (double)a.href;
+        const double pe = 0.5 * (double)a.grav * dh * dh;
+        const double v[NQ] = {ke, me, pe, fabs(uw), fabs(vs), fabs(AA(0, 0)), hc};
+        fold(acc, v);
+    }
+    block_reduce(acc, sm);
+    if (threadIdx.x == 0)
+        for (int q = 0; q < NQ; ++q) a.part[(long)blockIdx.x * NQ + q] = sm[0][q];
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void k_diag_final(DiagArgs<T> a) {
+    __shared__ double sm[NT][NQ];
+    double acc[NQ] = {0, 0, 0, 0, 0, 0, 1e300};
+    for (int b = threadIdx.x; b < NB; b += NT) fold(acc, a.part + (long)b * NQ);
+    block_reduce(acc, sm);
+    if (threadIdx.x == 0) {
+        const double cell = (double)a.dx * (double)a.dy;
+        a.out[0] = sm[0][0] * cell; a.out[1] = sm[0][1] * cell; a.out[2] = sm[0][2] * cell;
+        for (int q = 3; q < NQ; ++q) a.out[q] = sm[0][q];
+    }
+}
+
+}  // namespace
+
+template <typename T>
+hipError_t launch_diagnostics(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int j0, int j1, long sy, T dx, T dy,
+                              T grav, T href, int form, double *workspace, double *out, hipStream_t s) {
+    DiagArgs<T> a{q1, q2, h, A, Nx, Ny, j0, j1, sy, dx, dy, grav, href, form, workspace, out};
+    hipLaunchKernelGGL((k_diag_partial<T>), dim3(NB), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL((k_diag_final<T>), dim3(1), dim3(NT), 0, s, a);
+    return hipGetLastError();
+}
+template hipError_t launch_diagnostics<double>(const double *, const double *, const double *, const double *, int, int, int, int, long,
+                                               double, double, double, double, int, double *, double *, hipStream_t);
+template hipError_t launch_diagnostics<float>(const float *, const float *, const float *, const float *, int, int, int, int, long, float,
+                                              float, float, float, int, double *, double *, hipStream_t);
+
+}  // namespace swmhd

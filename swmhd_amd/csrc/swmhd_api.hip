@@ -134,6 +134,19 @@ int rk3_common(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int 
     return hiprc((flags & SWMHD_STRICT) ? launch_rk3_substep_strict<T>(a, s) : launch_rk3_substep_fast<T>(a, s));
 }
 
+template <typename T>
+int diag_common(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int Hx, int Hy, int64_t sy, T dx, T dy, T grav,
+                T href, int form, int j0, int j1, double *ws, double *out, void *stream) {
+    if (!q1 || !q2 || !h || !A || !ws || !out) return SWMHD_EINVAL;
+    if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx || !(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
+    if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
+    if (form != SWMHD_CONSERVATIVE && form != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
+    if (Hx < 1 || Hy < 1) return SWMHD_EHALO;
+    const long off = (long)Hy * sy + Hx;
+    return hiprc(launch_diagnostics<T>(q1 + off, q2 + off, h + off, A + off, Nx, Ny, j0, j1, (long)sy, dx, dy, grav, href, form, ws,
+                                       out, (hipStream_t)stream));
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,6 +199,11 @@ const char *swmhd_strerror(int rc) {
                                    T gamma, T zeta, int store_G, int j0, int j1, int flags, void *stream) {              \
         return tend_rk3_common<T>(q, qnew, Gn, Gm, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz, dt, gamma,   \
                                   zeta, store_G, j0, j1, flags, stream);                                                \
+    }                                                                                                                  \
+    int swmhd_diagnostics_##sfx(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int Hx, int Hy,      \
+                                int64_t sy, T dx, T dy, T g, T href, int form, int j0, int j1, double *ws, double *out, \
+                                void *stream) {                                                                        \
+        return diag_common<T>(q1, q2, h, A, Nx, Ny, Hx, Hy, sy, dx, dy, g, href, form, j0, j1, ws, out, stream);       \
     }                                                                                                                  \
     int swmhd_rk3_substep_##sfx(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy,   \
                                 int64_t sy, T dt, T gamma, T zeta, int j0, int j1, int flags, void *stream) {          \

@@ -162,6 +162,33 @@ class ShallowWaterModel:
         self.clock_time += dt
         self.iteration += 1
 
+    # --- diagnostics (SWMHD_example.jl:47-77): energies and extrema in one device pass ------------------------
+    def diagnostics(self, h_ref=1.0):
+        """dict(kinetic_energy, magnetic_energy, potential_energy, total_energy, max_abs_u, max_abs_v, max_abs_A, min_h)
+        over the whole (possibly decomposed) domain; energies as the reference's mean(...)*Lx*Ly."""
+        g = self.grid
+        if not hasattr(self, "_diag_ws"):
+            self._diag_ws = torch.empty(_lib.DIAG_WORKSPACE, dtype=torch.float64, device=self.fields[0].data.device)
+            self._diag_out = torch.empty(_lib.DIAG_NOUT, dtype=torch.float64, device=self.fields[0].data.device)
+        q = self.fields
+        f = getattr(self._L, f"swmhd_diagnostics_{self.sfx}")
+        rc = f(q[0].ptr, q[1].ptr, q[2].ptr, q[3].ptr, g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, g.dx, g.dy, self.g, h_ref,
+               self.form_code, 0, g.Ny, self._diag_ws.data_ptr(), self._diag_out.data_ptr(), _stream_ptr())
+        _lib.check(rc, "swmhd_diagnostics")
+        out = self._diag_out.clone()
+        if self.decomp.world_size > 1:   # the only collective in the package, 7 scalars, off the data path
+            import torch.distributed as dist
+            sums, maxs, mins = out[:3].clone(), out[3:6].clone(), out[6:].clone()
+            if sums.is_cuda and dist.get_backend(self.group) == "gloo":
+                sums, maxs, mins = sums.cpu(), maxs.cpu(), mins.cpu()
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(maxs, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(mins, op=dist.ReduceOp.MIN, group=self.group)
+            out = torch.cat([sums.cpu(), maxs.cpu(), mins.cpu()])
+        v = out.cpu().tolist()
+        return dict(kinetic_energy=v[0], magnetic_energy=v[1], potential_energy=v[2], total_energy=v[0] + v[1] + v[2],
+                    max_abs_u=v[3], max_abs_v=v[4], max_abs_A=v[5], min_h=v[6])
+
     def synchronize(self):
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
