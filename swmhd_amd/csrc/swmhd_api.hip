@@ -18,11 +18,9 @@ int lorentz_common(bool divergence, const T *A, const T *h, T *Fx, T *Fy, int Nx
     if (j_begin < 0 || j_end > Ny || j_begin > j_end) return SWMHD_EINVAL;
     const int need = divergence ? 3 : 2;
     if (Hx < need || Hy < need) return SWMHD_EHALO;
-    if (topo_x != SWMHD_PERIODIC || topo_y != SWMHD_PERIODIC) {
-        if ((topo_x != SWMHD_BOUNDED && topo_x != SWMHD_PERIODIC) || (topo_y != SWMHD_BOUNDED && topo_y != SWMHD_PERIODIC))
-            return SWMHD_EINVAL;
-        return SWMHD_ENOTSUP;  // Bounded wall branches: SURVEY.md 8(f) rank 3
-    }
+    if ((topo_x != SWMHD_BOUNDED && topo_x != SWMHD_PERIODIC) || (topo_y != SWMHD_BOUNDED && topo_y != SWMHD_PERIODIC))
+        return SWMHD_EINVAL;
+    if (!divergence && (topo_x != SWMHD_PERIODIC || topo_y != SWMHD_PERIODIC)) return SWMHD_EINVAL;
     if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL)) return SWMHD_EINVAL;
     if (j_begin == j_end) return SWMHD_OK;
     OpArgs<T> a;

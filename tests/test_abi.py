@@ -46,7 +46,7 @@ def test_argument_validation_without_gpu(swmhd):
     assert f(p, p, p, p, 4, 4, 2, 2, 8, 1.0, 1.0, 99, None) == 1            # unknown flags
     g = L.swmhd_lorentz_divergence_rows_f64
     assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 0, 0, 3, 2, 0, None) == 1  # j_begin > j_end
-    assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 1, 0, 0, 4, 0, None) == 3  # Bounded: ENOTSUP
+    assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 7, 0, 0, 4, 0, None) == 1  # unknown topology code
     assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 0, 0, 2, 2, 0, None) == 0  # empty row range is a no-op
 
 

@@ -157,6 +157,30 @@ def test_full_size_properties_4096(swmhd, form):
     assert torch.isfinite(Fx.data[I]).all() and Fx.data[I].abs().max().item() > 0
 
 
+@pytest.mark.parametrize("topo", [("Bounded", "Bounded"), ("Bounded", "Periodic"), ("Periodic", "Bounded")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(70, 50), (20, 18), (4, 3), (130, 9)])
+def test_bounded_wall_branches(swmhd, oracle, topo, dtype, shape):
+    """sw_mhd_divergence_functions.jl:42-53,66-77,90-101,114-125: `topology(grid, d) == Bounded` branches of the four fluxes.
+    Halos hold whatever the caller's boundary conditions put there (random here); strict = bitwise, fast within tolerance."""
+    Nx, Ny = shape
+    H = 3
+    A, h = Hh.random_case(Nx, Ny, H, H, 77 + Nx, dtype, periodic=False)
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, 0.37 * Nx), y=(0, 0.41 * Ny), halo=(H, H), topology=(topo[0], topo[1], "Flat"))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    f = {"A": swmhd.Field(g, dtype=tdt, data=torch.from_numpy(A).cuda()), "h": swmhd.Field(g, dtype=tdt, data=torch.from_numpy(h).cuda())}
+    code = {"Periodic": oracle.PERIODIC, "Bounded": oracle.BOUNDED}
+    want = oracle.lorentz_divergence(A, h, Nx, Ny, H, H, g.dx, g.dy, topo=(code[topo[0]], code[topo[1]]), nthreads=4)
+    periodic = oracle.lorentz_divergence(A, h, Nx, Ny, H, H, g.dx, g.dy, nthreads=4)
+    I = g.interior
+    got = _run(swmhd, "divergence", g, f, strict=True)
+    fast = _run(swmhd, "divergence", g, f, strict=False)
+    for w, q, r, p in zip(want, got, fast, periodic):
+        assert np.array_equal(w[I], q[I])
+        assert np.abs(w[I] - r[I]).max() <= TOL[dtype] * np.abs(w[I]).max()
+        assert not np.array_equal(w[I], p[I])      # the wall branches really are exercised
+
+
 def test_error_codes_on_device_pointers(swmhd):
     g = swmhd.RectilinearGrid(size=(16, 16), x=(0, 1), y=(0, 1), halo=(2, 2))
     A, h = swmhd.Field(g), swmhd.Field(g)
