@@ -129,7 +129,7 @@ def main():
                                    f"{'Jacobian' if args.formulation == 'VectorInvariant' else 'divergence'}-form Lorentz forcing, "
                                    "Bickley-jet h/u + current-sheet A (BASELINE config 3)" if args.formulation == "VectorInvariant"
                                    else f"{N}x{N} cells per GPU, periodic, Conservative formulation + divergence-form Lorentz forcing, two-Gaussian A (BASELINE config 4 ICs)",
-                       "step": "one RK3 time step = 3 x (fused tendency kernel + RK3 substep of 4 fields + halo fill)",
+                       "step": "one RK3 time step = 3 x (fused tendency+substep kernel, halo fill of 4 fields)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
                        "decomposition": f"y-slabs x{world} (ring halo exchange over RCCL, overlapped)" if world > 1 else "single GPU",
                        "dt": args.dt, "finite": finite},
@@ -138,11 +138,23 @@ def main():
             ms = [a.elapsed_time(b) for a, b in m.tendency_events]
             kern_ms = float(np.mean(ms))
             achieved = TEND_BYTES_PER_CELL * cells / (kern_ms * 1e-3) / 1e9
-            line["roofline"] = {"bound": "hbm", "kernel": "k_tendency (fused RHS of u,v,h,A incl. Lorentz force)", "achieved": achieved,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells, "avg_launch_ms": kern_ms,
-                                "launches_timed": len(ms),
-                                "whole_step_GBps": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9}
+            # PMC traffic cannot be collected inside this process; the per-launch figure measured with rocprofv3 --pmc on this
+            # same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note) is committed
+            # under profiles/ and echoed here when the workload matches
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "r01", "tendency_pmc_traffic.json")
+            if os.path.exists(tp) and N == 4096 and args.formulation == "VectorInvariant" and not args.strict:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch_corrected")
+            # the launch also performs the fused RK3 substep: besides the 64 B/cell of SURVEY 8(d) it reads G- and writes the
+            # new state (96 / 128 / 96 B/cell in stages 1 / 2 / 3); `achieved` stays on the conservative 64 B/cell figure
+            fused_bytes = (96 + 128 + 96) / 3.0 * cells
+            line["roofline"] = {"bound": "hbm", "kernel": "k_tendency_vi_march (fused RHS of u,v,h,A incl. Lorentz force + RK3 substep)",
+                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                "traffic": traffic, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells,
+                                "avg_launch_ms": kern_ms, "launches_timed": len(ms),
+                                "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
+                                "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,
+                                "note": "fp64 WENO5 makes this kernel VALU-bound (~640 fp64 VALU instr/cell-row-lane; see DESIGN.md 4)"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
