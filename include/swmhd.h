@@ -46,7 +46,8 @@ extern "C" {
 /* flags */
 #define SWMHD_FAST 0
 #define SWMHD_STRICT 1
-#define SWMHD_TILE_KERNEL 2   /* use the LDS-tiled kernel instead of the row-marching one (A/B measurements) */
+#define SWMHD_TILE_KERNEL 2   /* force the LDS-tiled kernel   (default: chosen by size -- tiles for small grids / thin strips, */
+#define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~2 Mcell up)                       */
 
 /* topology codes (Oceananigans.Grids.topology) */
 #define SWMHD_PERIODIC 0

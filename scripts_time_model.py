@@ -9,7 +9,7 @@ strict = len(sys.argv) > 3 and sys.argv[3] == "strict"
 cfg = configs.config3_bickley() if form == "VectorInvariant" else configs.config4_two_gaussians()
 g = S.RectilinearGrid(size=(N, N), x=cfg["domain"]["x"], y=cfg["domain"]["y"])
 tile = len(sys.argv) > 3 and sys.argv[3] == "tile"
-m = S.ShallowWaterModel(g, formulation=form, strict=strict, tile_kernel=tile)
+m = S.ShallowWaterModel(g, formulation=form, strict=strict, kernel=("tile" if tile else "march"))
 if form == "VectorInvariant":
     m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
 else:

@@ -19,5 +19,5 @@ def timeit(fn, n=30):
     return e0.elapsed_time(e1) / n
 for name, fn in (("jacobian", S.lorentz_force_func), ("divergence", S.div_lorentz)):
     for tile in (False, True):
-        t = timeit(lambda: fn(g, {"A": A, "h": h}, out=out, tile_kernel=tile))
+        t = timeit(lambda: fn(g, {"A": A, "h": h}, out=out, kernel=("tile" if tile else "march")))
         print(f"{name:10s} {'tile ' if tile else 'march'} N={N}: {t*1e3:7.1f} us  {32*N*N/t/1e6:7.0f} GB/s  ({32*N*N/t/1e6/80:.1f}% of 8 TB/s)")

@@ -10,6 +10,8 @@ _LIB = None
 STRICT = 1
 FAST = 0
 TILE_KERNEL = 2
+MARCH_KERNEL = 4
+KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4}
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
 DIAG_NOUT, DIAG_WORKSPACE = 7, 1024 * 7

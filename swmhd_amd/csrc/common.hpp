@@ -21,7 +21,7 @@ struct OpArgs {
     T dx, dy, rdx, rdy;
     int j0, j1;  // rows [j0, j1) are computed (0-based)
     int topo_x, topo_y;
-    int kernel_variant;  // 0 = default (row-marching in fast builds), 1 = LDS-tiled kernel
+    int kernel_variant;  // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
 };
 
 // launchers, one pair per translation unit (fast: reciprocal multiplies + FMA; strict: reference op order,
@@ -50,7 +50,7 @@ struct TendArgs {
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
-    int kernel_variant;   // 0 = default (row-marching where available), 1 = LDS-tiled kernel (A/B measurements, strict builds)
+    int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;

@@ -62,6 +62,19 @@ class Field:
     def ptr(self):
         return self.data.data_ptr()
 
+    # --- dump / restore incl. halos (the reference writes fields `with_halos = true`,
+    #     divergence_formulation/divergence_sw_mhd.jl:78-82).  Raw .npy of the parent, shape (Ny+2Hy, Nx+2Hx): transposing it
+    #     gives Julia's (Nx+2Hx, Ny+2Hy) parent, so a real Oceananigans run can be diffed against it wherever Julia exists.
+    def save(self, path):
+        np.save(path, self.numpy())
+
+    def load(self, path):
+        arr = np.load(path, allow_pickle=False)
+        if tuple(arr.shape) != self.grid.parent_shape:
+            raise ValueError(f"{path}: shape {arr.shape} != parent shape {self.grid.parent_shape}")
+        self.data.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(self.data.dtype))
+        return self
+
     def interior(self):
         return self.data[self.grid.interior]
 

@@ -20,7 +20,7 @@ def _get(fields, name):
     return fields[name] if isinstance(fields, dict) else getattr(fields, name)
 
 
-def _call(form, grid, fields, out, strict, rows, stream, tile_kernel=False):
+def _call(form, grid, fields, out, strict, rows, stream, kernel="auto"):
     A, h = _get(fields, "A"), _get(fields, "h")
     if not (A.data.is_cuda and h.data.is_cuda):
         raise _lib.SwmhdError("swmhd_amd operators run on the GPU only (no CPU fallback); got a host tensor")
@@ -31,7 +31,7 @@ def _call(form, grid, fields, out, strict, rows, stream, tile_kernel=False):
     Fx, Fy = out
     assert Fx.stride_y == A.stride_y and Fy.stride_y == A.stride_y
     sfx = _SFX[A.data.dtype]
-    flags = (_lib.STRICT if strict else _lib.FAST) | (_lib.TILE_KERNEL if tile_kernel else 0)
+    flags = (_lib.STRICT if strict else _lib.FAST) | _lib.KERNEL_FLAGS[kernel]
     j0, j1 = (0, g.Ny) if rows is None else rows
     L = _lib.lib()
     sp = _stream_ptr(stream)
@@ -46,11 +46,11 @@ def _call(form, grid, fields, out, strict, rows, stream, tile_kernel=False):
     return Fx, Fy
 
 
-def lorentz_force_func(grid, fields, out=None, strict=False, rows=None, stream=None, tile_kernel=False):
+def lorentz_force_func(grid, fields, out=None, strict=False, rows=None, stream=None, kernel="auto"):
     """(lorentz_force_func_x, lorentz_force_func_y) for all interior cells -- Jacobian formulation."""
-    return _call("jacobian", grid, fields, out, strict, rows, stream, tile_kernel)
+    return _call("jacobian", grid, fields, out, strict, rows, stream, kernel)
 
 
-def div_lorentz(grid, fields, out=None, strict=False, rows=None, stream=None, tile_kernel=False):
+def div_lorentz(grid, fields, out=None, strict=False, rows=None, stream=None, kernel="auto"):
     """(div_lorentz_x, div_lorentz_y) for all interior cells -- divergence (Maxwell-stress) formulation."""
-    return _call("divergence", grid, fields, out, strict, rows, stream, tile_kernel)
+    return _call("divergence", grid, fields, out, strict, rows, stream, kernel)

@@ -57,8 +57,8 @@ def test_strict_is_bitwise_and_fast_within_tolerance(swmhd, oracle, form, dtype,
     I = g.interior
     for w, q in zip(want, got):
         assert np.array_equal(w[I], q[I]), f"strict {form} differs from oracle: max {np.abs(w[I]-q[I]).max()}"
-    for tile in (False, True):   # default fast path = row-marching kernel; tile_kernel=True = LDS-tiled fast kernel
-        fast = _run(swmhd, form, g, f, strict=False, tile_kernel=tile)
+    for tile in (False, True):   # both fast kernels: row-marching and LDS-tiled
+        fast = _run(swmhd, form, g, f, strict=False, kernel=("tile" if tile else "march"))
         for w, q in zip(want, fast):
             assert np.abs(w[I] - q[I]).max() <= TOL[dtype] * max(np.abs(w[I]).max(), 1e-300), ("tile" if tile else "march")
 
