@@ -1,6 +1,6 @@
 """Scratch timing of the fused engine (not part of the contract): python scripts_time_model.py [N] [form]"""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import swmhd_amd as S
 from swmhd_amd import configs
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
