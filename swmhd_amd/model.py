@@ -138,12 +138,14 @@ class ShallowWaterModel:
             # one RK3 stage over a row range: either the fused kernel or tendencies followed (later) by the substep
             run = (lambda rows=None: self._stage_fused(dt, stage, rows)) if self.fused else (lambda rows=None: self.calculate_tendencies(rows=rows))
             if overlap and self.iteration + stage > 0:
-                # x halos are current; the y exchange of the previous stage is in flight on the comm stream ->
-                # interior rows first, the two boundary strips after the exchange has landed
+                # x halos are current; the y exchange of the previous stage is in flight on the comm stream.  Interior rows run
+                # on the main stream; the two H-row boundary strips are queued on the COMM stream behind the exchange, so they
+                # start the moment the halo rows land and overlap the tail of the interior kernel.
                 run((H, g.Ny - H))
+                with torch.cuda.stream(self._comm_stream):
+                    run((0, H))
+                    run((g.Ny - H, g.Ny))
                 torch.cuda.current_stream().wait_stream(self._comm_stream)
-                run((0, H))
-                run((g.Ny - H, g.Ny))
             else:
                 run()
             if self.fused:
