@@ -164,6 +164,41 @@ class ShallowWaterModel:
         self.clock_time += dt
         self.iteration += 1
 
+    # --- HIP-graph replay of the step (single GPU): the reference's own grids are 64^2 .. 128^2 (SWMHD_example.jl:11), where a
+    #     step is 6 launches of ~10 us kernels and the host would otherwise set the pace --------------------------------
+    def capture_graph(self, dt):
+        """Capture TWO RK3 steps (6 fused stages + 6 halo fills) into one HIP graph; two, because the ping-ponged state and the
+        G-/Gn pointers return to their original roles after an even number of stages.  `time_steps` then replays it."""
+        if self.decomp.world_size != 1 or not self.fused:
+            raise _lib.SwmhdError("capture_graph: single-GPU fused path only (halo exchange is not capturable)")
+        keep = [f.data.clone() for f in self.fields] + [f.data.clone() for f in self.Gm]
+        t0, i0 = self.clock_time, self.iteration
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up outside capture (lazy module loads etc.)
+            self.time_step(dt); self.time_step(dt)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self.time_step(dt); self.time_step(dt)
+        self._graph_dt = dt
+        for f, k in zip(self.fields + self.Gm, keep):   # capture does not execute; undo the two warm-up steps
+            f.data.copy_(k)
+        self.clock_time, self.iteration = t0, i0
+        return self
+
+    def time_steps(self, n, dt):
+        """n RK3 steps: graph replays (2 steps each) when a graph was captured for this dt, eager steps otherwise."""
+        g = getattr(self, "_graph", None)
+        if g is not None and self._graph_dt == dt and self.iteration > 0:
+            for _ in range(n // 2):
+                g.replay()
+                self.clock_time += 2 * dt
+                self.iteration += 2
+            n = n % 2
+        for _ in range(n):
+            self.time_step(dt)
+
     # --- diagnostics (SWMHD_example.jl:47-77): energies and extrema in one device pass ------------------------
     def diagnostics(self, h_ref=1.0):
         """dict(kinetic_energy, magnetic_energy, potential_energy, total_energy, max_abs_u, max_abs_v, max_abs_A, min_h)

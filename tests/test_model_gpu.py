@@ -242,3 +242,24 @@ def test_baseline_slab_sizes_size_independent_properties(swmhd, form, shape):
     for a, b in zip(*outs):
         ref = torch.roll(a, 517, 1)
         assert (ref - b).abs().max().item() <= 1e-11 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("form", [1, 0])
+def test_graph_replay_equals_eager(swmhd, form):
+    """HIP-graph replay of the step (capture_graph / time_steps) is bit-identical to eager stepping, on the reference's own
+    grid size (64 x 64, SWMHD_example.jl:11)."""
+    N = 64
+    q, _, dx, dy = staggered_fields(N, form)
+    q = [Hh.fill_halo_periodic(a, N, N, 3, 3) for a in q]
+    a = make_model(swmhd, N, N, form, 2 - form, q, dx, dy, strict=False)
+    b = make_model(swmhd, N, N, form, 2 - form, q, dx, dy, strict=False)
+    dt = 0.002
+    a.time_step(dt); b.time_step(dt)            # iteration 0 takes the eager path in both
+    b.capture_graph(dt)
+    for _ in range(9):
+        a.time_step(dt)
+    b.time_steps(9, dt)                          # 4 replays + 1 eager step
+    a.synchronize(); b.synchronize()
+    for fa, fb in zip(a.fields, b.fields):
+        assert torch.equal(fa.data, fb.data)
+    assert a.iteration == b.iteration == 10 and abs(a.clock_time - b.clock_time) < 1e-15
