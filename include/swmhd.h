@@ -190,6 +190,26 @@ int swmhd_tendencies_rk3_f32(const float *const *q, float *const *qnew, float *c
                              int j_begin, int j_end, int flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Native step driver: `nsteps` complete RK3 time steps of the periodic single-GPU model, i.e. Oceananigans'
+ * time_step!(model, dt) (timestepper = :RungeKutta3, SWMHD_example.jl:23,42 / divergence_sw_mhd.jl:20,39) repeated:
+ *     3 x { swmhd_tendencies_rk3 (gamma, zeta of the stage) ; swap state sets ; swap G sets ; periodic halo fill }
+ * All 6*nsteps launches are enqueued on `stream` by this one call (capturable into a HIP graph).
+ *   q      HOST array of 4 parents (u|uh, v|vh, h, A): the current state, halos filled
+ *   q_alt  second set of 4 parents (scratch on entry)
+ *   Ga,Gb  two sets of 4 tendency parents (scratch)
+ * On return the state is in q if *state_in_alt == 0, in q_alt otherwise (an RK3 step swaps the sets three times, so
+ * nsteps odd <=> state_in_alt = 1).  state_in_alt may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_step_rk3_f64(double *const *q, double *const *q_alt, double *const *Ga, double *const *Gb,
+                       int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
+                       double g, double f, int formulation, int lorentz, double dt, int nsteps,
+                       int flags, int *state_in_alt, void *stream);
+int swmhd_step_rk3_f32(float *const *q, float *const *q_alt, float *const *Ga, float *const *Gb,
+                       int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
+                       float g, float f, int formulation, int lorentz, float dt, int nsteps,
+                       int flags, int *state_in_alt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Energy and extrema diagnostics, one pass (the reference computes them every iteration:
  * kinetic/magnetic/potential_energy_func SWMHD_example.jl:67-77 / divergence_sw_mhd.jl:63-74 written by the
  * NetCDFOutputWriter :87-92, and max|u|, max|A|, min h in the progress callback :47-65).

@@ -1,0 +1,99 @@
+# SWMHDAmd.jl -- Julia binding of libswmhd.so (include/swmhd.h) for the reference's two driver scripts.
+#
+# TEXT DELIVERABLE: there is no Julia toolchain (and no Oceananigans) in the build image or on the GPU box, so this file has
+# never been executed.  It is the glue a maintainer of writingindy/SWMHD would add; every ccall below matches a prototype in
+# include/swmhd.h one to one, and the Python/ctypes binding swmhd_amd/_lib.py (which IS tested) makes the same calls.
+#
+# What it replaces in the reference:
+#   jacobian_formulation/SWMHD_example.jl:30-31     forcing = (u = Forcing(lorentz_force_func_x, discrete_form=true), v = ...)
+#   divergence_formulation/divergence_sw_mhd.jl:28-29  forcing = (uh = Forcing(div_lorentz_x, ...), vh = ...)
+# The forcing keeps its discrete-form signature f(i, j, k, grid, clock, fields, parameters) and just reads an auxiliary field
+# that one whole-field kernel launch fills (the per-cell functions of sw_mhd_jacobian_functions.jl / sw_mhd_divergence_functions.jl
+# are evaluated for all cells at once on the GPU).
+module SWMHDAmd
+
+using Oceananigans, AMDGPU
+
+const libswmhd = get(ENV, "SWMHD_LIB", joinpath(@__DIR__, "..", "swmhd_amd", "libswmhd.so"))
+
+const SWMHD_FAST, SWMHD_STRICT = Cint(0), Cint(1)
+const CONSERVATIVE, VECTOR_INVARIANT = Cint(0), Cint(1)
+const LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = Cint(0), Cint(1), Cint(2)
+
+check(rc) = rc == 0 || error(unsafe_string(ccall((:swmhd_strerror, libswmhd), Cstring, (Cint,), rc)))
+
+# parent pointer, extents and stride of a halo-padded Oceananigans field (column-major (Nx+2Hx, Ny+2Hy, 1) parent)
+pp(f) = pointer(parent(f))
+stride_y(f) = Int64(size(parent(f), 1))
+hipstream() = AMDGPU.stream().stream
+
+"Fill (Fx, Fy) with lorentz_force_func_x/y for every interior cell (sw_mhd_jacobian_functions.jl:20-26)."
+function lorentz_jacobian!(Fx, Fy, A, h, grid; flags = SWMHD_FAST)
+    check(ccall((:swmhd_lorentz_jacobian_f64, libswmhd), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Cint, Int64, Float64, Float64, Cint, Ptr{Cvoid}),
+                pp(A), pp(h), pp(Fx), pp(Fy), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(A), grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, flags, hipstream()))
+end
+
+"Fill (Fx, Fy) with div_lorentz_x/y for every interior cell (sw_mhd_divergence_functions.jl:162-170)."
+function lorentz_divergence!(Fx, Fy, A, h, grid; flags = SWMHD_FAST)
+    check(ccall((:swmhd_lorentz_divergence_f64, libswmhd), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Cint, Int64, Float64, Float64, Cint, Ptr{Cvoid}),
+                pp(A), pp(h), pp(Fx), pp(Fy), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(A), grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, flags, hipstream()))
+end
+
+# the forcing callbacks keep the reference's signature; `p` carries the auxiliary field
+@inline lorentz_x(i, j, k, grid, clock, fields, p) = @inbounds p.Fx[i, j, k]
+@inline lorentz_y(i, j, k, grid, clock, fields, p) = @inbounds p.Fy[i, j, k]
+
+"""
+    mhd_shallow_water_model(grid; formulation) -> (model, update!)
+
+The model of SWMHD_example.jl:21-33 (VectorInvariantFormulation) or divergence_sw_mhd.jl:19-31 (ConservativeFormulation) with
+the MHD forcing evaluated by libswmhd.  Call `update!(model)` after every halo fill (Oceananigans >= 0.80:
+`add_callback!(simulation, update!, callsite = UpdateStateCallsite())`).
+"""
+function mhd_shallow_water_model(grid; formulation = VectorInvariantFormulation(), g = 9.81, f = 1)
+    Fx, Fy = XFaceField(grid), YFaceField(grid)
+    jac = formulation isa VectorInvariantFormulation
+    names = jac ? (:u, :v) : (:uh, :vh)
+    forcing = NamedTuple{names}((Forcing(lorentz_x, discrete_form = true, parameters = (; Fx)),
+                                 Forcing(lorentz_y, discrete_form = true, parameters = (; Fy))))
+    model = ShallowWaterModel(; grid, timestepper = :RungeKutta3, gravitational_acceleration = g, coriolis = FPlane(f = f),
+                              momentum_advection = jac ? WENO5(vector_invariant = VelocityStencil()) : WENO5(),
+                              mass_advection = WENO5(), tracer_advection = WENO5(), tracers = (:A,), forcing, formulation)
+    update!(m) = jac ? lorentz_jacobian!(Fx, Fy, m.tracers.A, m.solution.h, grid) :
+                       lorentz_divergence!(Fx, Fy, m.tracers.A, m.solution.h, grid)
+    return model, update!
+end
+
+"""
+    native_steps!(q, q_alt, Ga, Gb, grid, Δt, n; formulation, lorentz) -> state_in_alt::Bool
+
+Hand `n` whole RK3 steps to the engine (swmhd_step_rk3_f64): q, q_alt are 4-tuples of fields (u|uh, v|vh, h, A) -- current state
+and a scratch copy --, Ga, Gb two 4-tuples of tendency fields.  Periodic single-GPU grids.  The base right-hand side inside is a
+restatement of Oceananigans' scheme that could not be checked against the library (DESIGN.md section 3).
+"""
+function native_steps!(q, q_alt, Ga, Gb, grid, Δt, n; formulation = VECTOR_INVARIANT, lorentz = LORENTZ_JACOBIAN, g = 9.81, f = 1.0,
+                       flags = SWMHD_FAST)
+    ptrs(t) = Ptr{Float64}[pp(x) for x in t]
+    swapped = Ref{Cint}(0)
+    check(ccall((:swmhd_step_rk3_f64, libswmhd), Cint,
+                (Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Cint, Cint, Cint, Cint, Int64,
+                 Float64, Float64, Float64, Float64, Cint, Cint, Float64, Cint, Cint, Ptr{Cint}, Ptr{Cvoid}),
+                ptrs(q), ptrs(q_alt), ptrs(Ga), ptrs(Gb), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]),
+                grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, g, f, formulation, lorentz, Δt, n, flags, swapped, hipstream()))
+    return swapped[] != 0
+end
+
+"Energies and extrema in one device pass: (KE, ME, PE, max|u|, max|v|, max|A|, min h), SWMHD_example.jl:47-77."
+function diagnostics(q, grid; formulation = VECTOR_INVARIANT, g = 9.81, h_ref = 1.0)
+    ws, out = AMDGPU.zeros(Float64, 1024 * 7), AMDGPU.zeros(Float64, 7)
+    check(ccall((:swmhd_diagnostics_f64, libswmhd), Cint,
+                (Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Cint, Cint, Int64, Float64, Float64, Float64,
+                 Float64, Cint, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                pp(q[1]), pp(q[2]), pp(q[3]), pp(q[4]), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]), grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ,
+                g, h_ref, formulation, 0, grid.Ny, pointer(ws), pointer(out), hipstream()))
+    return Array(out)
+end
+
+end # module

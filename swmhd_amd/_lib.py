@@ -56,6 +56,9 @@ def _declare(lib):
         f = getattr(lib, f"swmhd_tendencies_rk3_{sfx}")
         f.argtypes = [C.POINTER(p)] * 4 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, ft, ft, ft, i, i, i, i, p]
         f.restype = i
+        f = getattr(lib, f"swmhd_step_rk3_{sfx}")
+        f.argtypes = [C.POINTER(p)] * 4 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, ft, i, i, C.POINTER(i), p]
+        f.restype = i
         f = getattr(lib, f"swmhd_diagnostics_{sfx}")
         f.argtypes = [p, p, p, p, i, i, i, i, i64, ft, ft, ft, ft, i, i, i, p, p, p]
         f.restype = i
@@ -68,7 +71,7 @@ def _declare(lib):
 EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
-        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "diagnostics")]
+        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics")]
 
 
 def lib():

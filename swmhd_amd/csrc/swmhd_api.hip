@@ -133,6 +133,35 @@ int rk3_common(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int 
 }
 
 template <typename T>
+int step_common(T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny, int Hx, int Hy, int64_t sy, T dx, T dy, T grav,
+                T fcor, int formulation, int lorentz, T dt, int nsteps, int flags, int *state_in_alt, void *stream) {
+    if (!q || !q_alt || !Ga || !Gb || nsteps < 0) return SWMHD_EINVAL;
+    // RungeKutta3 coefficients (Oceananigans TimeSteppers: gamma = 8/15, 5/12, 3/4; zeta = -, -17/60, -5/12)
+    const T gam[3] = {T(8.0 / 15.0), T(5.0 / 12.0), T(3.0 / 4.0)};
+    const T zet[3] = {T(0), T(-17.0 / 60.0), T(-5.0 / 12.0)};
+    T *cur[4], *alt[4], *gn[4], *gm[4];
+    for (int f = 0; f < 4; ++f) {
+        if (!q[f] || !q_alt[f] || !Ga[f] || !Gb[f]) return SWMHD_EINVAL;
+        cur[f] = q[f]; alt[f] = q_alt[f]; gn[f] = Ga[f]; gm[f] = Gb[f];
+    }
+    int swaps = 0;
+    for (int n = 0; n < nsteps; ++n)
+        for (int st = 0; st < 3; ++st) {
+            const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
+            const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+            int rc = tend_rk3_common<T>(cq, alt, gn, st == 0 ? nullptr : cgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation,
+                                        lorentz, dt, gam[st], zet[st], st < 2 ? 1 : 0, 0, Ny, flags, stream);
+            if (rc) return rc;
+            for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
+            ++swaps;
+            rc = halo_multi_common<T>(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X | SWMHD_HALO_Y, stream);
+            if (rc) return rc;
+        }
+    if (state_in_alt) *state_in_alt = swaps & 1;
+    return SWMHD_OK;
+}
+
+template <typename T>
 int diag_common(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int Hx, int Hy, int64_t sy, T dx, T dy, T grav,
                 T href, int form, int j0, int j1, double *ws, double *out, void *stream) {
     if (!q1 || !q2 || !h || !A || !ws || !out) return SWMHD_EINVAL;
@@ -202,6 +231,12 @@ const char *swmhd_strerror(int rc) {
                                 int64_t sy, T dx, T dy, T g, T href, int form, int j0, int j1, double *ws, double *out, \
                                 void *stream) {                                                                        \
         return diag_common<T>(q1, q2, h, A, Nx, Ny, Hx, Hy, sy, dx, dy, g, href, form, j0, j1, ws, out, stream);       \
+    }                                                                                                                  \
+    int swmhd_step_rk3_##sfx(T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny, int Hx, int Hy,   \
+                             int64_t sy, T dx, T dy, T g, T f, int formulation, int lorentz, T dt, int nsteps, int flags,\
+                             int *state_in_alt, void *stream) {                                                        \
+        return step_common<T>(q, q_alt, Ga, Gb, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz, dt, nsteps, flags, \
+                              state_in_alt, stream);                                                                   \
     }                                                                                                                  \
     int swmhd_rk3_substep_##sfx(T *const *U, const T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy,   \
                                 int64_t sy, T dt, T gamma, T zeta, int j0, int j1, int flags, void *stream) {          \

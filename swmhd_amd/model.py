@@ -188,7 +188,8 @@ class ShallowWaterModel:
         return self
 
     def time_steps(self, n, dt):
-        """n RK3 steps: graph replays (2 steps each) when a graph was captured for this dt, eager steps otherwise."""
+        """n RK3 steps: graph replays (2 steps each) when a graph was captured for this dt; otherwise the native step driver
+        (swmhd_step_rk3_*: one C call enqueues all 6n launches) on a single GPU, or Python-driven stages on several."""
         g = getattr(self, "_graph", None)
         if g is not None and self._graph_dt == dt and self.iteration > 0:
             for _ in range(n // 2):
@@ -196,6 +197,24 @@ class ShallowWaterModel:
                 self.clock_time += 2 * dt
                 self.iteration += 2
             n = n % 2
+        if n > 0 and self.decomp.world_size == 1 and self.fused and self.tendency_events is None:
+            gr = self.grid
+            import ctypes
+            swapped = ctypes.c_int(0)
+            q = _lib.ptr_array([f.ptr for f in self.fields])
+            qa = _lib.ptr_array([self._alt[nm].ptr for nm in self.names])
+            Ga = _lib.ptr_array([f.ptr for f in self.Gn])
+            Gb = _lib.ptr_array([f.ptr for f in self.Gm])
+            f = getattr(self._L, f"swmhd_step_rk3_{self.sfx}")
+            rc = f(q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self.fields[0].stride_y, gr.dx, gr.dy, self.g, self.f, self.form_code,
+                   self.lorentz_code, dt, n, self._flags, ctypes.byref(swapped), _stream_ptr())
+            _lib.check(rc, "swmhd_step_rk3")
+            if swapped.value:
+                self.solution, self._alt = self._alt, self.solution
+                self.Gn, self.Gm = self.Gm, self.Gn
+            self.clock_time += n * dt
+            self.iteration += n
+            return
         for _ in range(n):
             self.time_step(dt)
 
