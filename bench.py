@@ -155,6 +155,24 @@ def main():
                                 "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                 "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,
                                 "note": "fp64 WENO5 makes this kernel VALU-bound (~640 fp64 VALU instr/cell-row-lane; see DESIGN.md 4)"}
+        if world == 1:
+            # the reference's own hot-path kernel (whole-field Lorentz force, 32 B/cell: read A,h, write Fx,Fy) on the same fields,
+            # timed with HIP events outside the step's timed region
+            op = S.lorentz_force_func if args.formulation == "VectorInvariant" else S.div_lorentz
+            fld = {"A": m.solution["A"], "h": m.solution["h"]}
+            out = (S.Field(g), S.Field(g))
+            for _ in range(5):
+                op(g, fld, out=out, strict=args.strict)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(30):
+                op(g, fld, out=out, strict=args.strict)
+            e1.record(); torch.cuda.synchronize()
+            op_ms = e0.elapsed_time(e1) / 30
+            op_bw = 32 * cells / (op_ms * 1e-3) / 1e9
+            line["lorentz_operator"] = {"kernel": "k_lorentz_jacobian_march" if args.formulation == "VectorInvariant" else "k_lorentz_divergence_march",
+                                        "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": op_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 32 * cells}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)

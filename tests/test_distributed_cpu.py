@@ -26,7 +26,7 @@ def _worker(rank, world, port, form, lor, nsteps, out):
         from oracle import oracle as O
         from swmhd_amd import SlabDecomposition, exchange_y_halos, RectilinearGrid
         from test_model_oracle import staggered_fields, G, F
-        N, H = 32, 3
+        N, H = 12 * world, 3
         q, _, dx, dy = staggered_fields(N, form)
         q = [O.fill_halo_periodic(a, N, N, H, H) for a in q]
         dec = SlabDecomposition(N, world, rank)
@@ -58,12 +58,15 @@ def _worker(rank, world, port, form, lor, nsteps, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
-def test_two_rank_slab_run_equals_single_domain(oracle, tmp_path, form, lor):
+def test_slab_run_equals_single_domain(oracle, tmp_path, form, lor, world):
+    """world 2: both ring neighbours are the same peer (two sends + two recvs to one rank in one batch);
+    world 3: distinct north / south peers."""
     from test_model_oracle import staggered_fields, G, F
-    world, nsteps = 2, 2
+    nsteps = 2
     mp.spawn(_worker, args=(world, _free_port(), form, lor, nsteps, str(tmp_path)), nprocs=world, join=True)
-    N, H = 32, 3
+    N, H = 12 * world, 3
     q, _, dx, dy = staggered_fields(N, form)
     q = [oracle.fill_halo_periodic(a, N, N, H, H) for a in q]
     for _ in range(nsteps):
