@@ -47,6 +47,7 @@ extern "C" {
 #define SWMHD_FAST 0
 #define SWMHD_STRICT 1
 #define SWMHD_TILE_KERNEL 2   /* force the LDS-tiled kernel   (default: chosen by size -- tiles for small grids / thin strips, */
+#define SWMHD_SPLIT_KERNEL 8  /* tendency entry points, vector-invariant model: wave-specialised row-marching kernel (A/B)     */
 #define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~2 Mcell up)                       */
 
 /* topology codes (Oceananigans.Grids.topology) */

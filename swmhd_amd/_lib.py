@@ -11,7 +11,8 @@ STRICT = 1
 FAST = 0
 TILE_KERNEL = 2
 MARCH_KERNEL = 4
-KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4}
+SPLIT_KERNEL = 8
+KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4, "split": 8}
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
 DIAG_NOUT, DIAG_WORKSPACE = 7, 1024 * 7
