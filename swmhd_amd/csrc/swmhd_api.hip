@@ -75,7 +75,8 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
-    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_SPLIT_KERNEL)) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_SPLIT_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y)) return SWMHD_EINVAL;
+    if ((flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) && (!rk || Hx > Nx || Hy > Ny)) return rk ? SWMHD_EHALO : SWMHD_EINVAL;
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
     const bool ok = lorentz == SWMHD_LORENTZ_NONE || (formulation == SWMHD_VECTOR_INVARIANT && lorentz == SWMHD_LORENTZ_JACOBIAN) ||
@@ -90,6 +91,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
     a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
+    a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : ((flags & SWMHD_SPLIT_KERNEL) ? 3 : 0));
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
     if (rk) {
@@ -154,8 +156,11 @@ int step_common(T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx
             if (rc) return rc;
             for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
             ++swaps;
-            rc = halo_multi_common<T>(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X | SWMHD_HALO_Y, stream);
-            if (rc) return rc;
+            const int need = (SWMHD_HALO_X | SWMHD_HALO_Y) & ~(((flags & SWMHD_WRAP_X) ? SWMHD_HALO_X : 0) | ((flags & SWMHD_WRAP_Y) ? SWMHD_HALO_Y : 0));
+            if (need) {   // whatever the kernel did not wrap itself
+                rc = halo_multi_common<T>(cur, 4, Nx, Ny, Hx, Hy, sy, need, stream);
+                if (rc) return rc;
+            }
         }
     if (state_in_alt) *state_in_alt = swaps & 1;
     return SWMHD_OK;

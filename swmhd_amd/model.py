@@ -23,7 +23,7 @@ RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True, fused=True, kernel="auto"):
+                 overlap=True, fused=True, kernel="auto", fuse_halo=True):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -41,6 +41,11 @@ class ShallowWaterModel:
         mk = lambda loc: Field(grid, loc, dtype, device)
         self.solution = {n: mk(l) for n, l in zip(self.names, locs)}
         self.fused = fused                    # one kernel per RK3 stage (tendencies + substep), state ping-ponged
+        # periodic halo fill fused into the stage kernel ("scatter on write"): x and y images on one GPU, x images on a slab
+        self._wrap = 0
+        # Only where the tile kernel runs anyway (small grids): the marching kernels keep the separate 5-us halo launch.
+        if fused and fuse_halo and grid.Nx >= grid.Hx and grid.Ny >= grid.Hy and grid.Nx * grid.Ny <= 300000 and kernel in (None, "auto", "tile"):
+            self._wrap = _lib.WRAP_X | (_lib.WRAP_Y if (decomp is None or decomp.world_size == 1) else 0)
         self._alt = {n: mk(l) for n, l in zip(self.names, locs)} if fused else None
         self.Gn = [mk(l) for l in locs]     # Gⁿ
         self.Gm = [mk(l) for l in locs]     # G⁻
@@ -123,7 +128,7 @@ class ShallowWaterModel:
             e0.record()
         rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
                self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
-               self._flags, _stream_ptr())
+               self._flags | self._wrap, _stream_ptr())
         if timed:
             e1.record()
             self.tendency_events.append((e0, e1))
@@ -153,7 +158,8 @@ class ShallowWaterModel:
             else:
                 self._substep(dt, stage)
             self.Gn, self.Gm = self.Gm, self.Gn          # store_tendencies!: G⁻ <- Gⁿ (pointer swap, 0 bytes)
-            self._fill_x()
+            if not (self.fused and self._wrap):
+                self._fill_x()                           # (the fused kernel already wrote the periodic images otherwise)
             if multi:
                 if overlap:
                     self._comm_stream.wait_stream(torch.cuda.current_stream())
@@ -207,7 +213,7 @@ class ShallowWaterModel:
             Gb = _lib.ptr_array([f.ptr for f in self.Gm])
             f = getattr(self._L, f"swmhd_step_rk3_{self.sfx}")
             rc = f(q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self.fields[0].stride_y, gr.dx, gr.dy, self.g, self.f, self.form_code,
-                   self.lorentz_code, dt, n, self._flags, ctypes.byref(swapped), _stream_ptr())
+                   self.lorentz_code, dt, n, self._flags | self._wrap, ctypes.byref(swapped), _stream_ptr())
             _lib.check(rc, "swmhd_step_rk3")
             if swapped.value:
                 self.solution, self._alt = self._alt, self.solution
