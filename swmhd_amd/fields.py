@@ -23,7 +23,8 @@ class Field:
         self.grid, self.loc = grid, loc
         if data is None:
             data = torch.zeros(grid.parent_shape, dtype=dtype, device=device)
-        assert tuple(data.shape) == grid.parent_shape and data.is_contiguous()
+        # rows may be pitched (stride_y > Nx+2Hx, e.g. a column slice of a wider allocation); x must be unit-stride
+        assert tuple(data.shape) == grid.parent_shape and data.stride(1) == 1 and data.stride(0) >= data.shape[1]
         self.data = data
 
     # --- reference-style helpers -------------------------------------------------------------

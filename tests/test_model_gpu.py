@@ -318,3 +318,54 @@ def test_marching_kernels_are_deterministic_and_stable_at_4096(swmhd, form):
     d = ms[0].diagnostics()
     assert all(np.isfinite(v) for v in d.values())
     assert abs(d["total_energy"] - e0) <= 1e-3 * abs(e0)
+
+
+@pytest.mark.parametrize("form,lor", [(1, 1), (0, 2)])
+@pytest.mark.parametrize("halo", [(4, 5), (5, 3)])
+def test_wider_halos_and_pitched_rows(swmhd, oracle, form, lor, halo):
+    """Hx != Hy > 3 and a row pitch larger than Nx+2Hx (the C-ABI's stride_y): every fast kernel and the strict kernel, Lorentz
+    operators and fused tendencies, against the oracle evaluated on a dense copy."""
+    Nx, Ny = 300, 41
+    Hx, Hy = halo
+    rng = np.random.default_rng(17)
+    shp = (Ny + 2 * Hy, Nx + 2 * Hx)
+    h = 1.0 + 0.3 * rng.random(shp); u = 0.5 * rng.standard_normal(shp); v = 0.5 * rng.standard_normal(shp); A = rng.standard_normal(shp)
+    q = [u, v, h, A] if form == 1 else [h * u, h * v, h, A]
+    q = [np.ascontiguousarray(Hh.fill_halo_periodic(a, Nx, Ny, Hx, Hy)) for a in q]
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, 0.11 * Nx), y=(0, 0.13 * Ny), halo=(Hx, Hy))
+    W, pitch = shp[1], shp[1] + 7
+
+    def pitched(a=None):
+        buf = torch.full((shp[0], pitch), -9.5, dtype=torch.float64, device="cuda")
+        view = buf[:, :W]
+        if a is not None:
+            view.copy_(torch.from_numpy(a))
+        return swmhd.Field(g, data=view), buf
+
+    want = oracle.tendencies(*q, Nx, Ny, Hx, Hy, g.dx, g.dy, form, lor, G, F, nthreads=8)
+    opw = (oracle.lorentz_jacobian if form == 1 else oracle.lorentz_divergence)(q[3], q[2], Nx, Ny, Hx, Hy, g.dx, g.dy, nthreads=8)
+    I = g.interior
+    for kern, strict in (("tile", True), ("tile", False), ("march", False)) + ((("split", False),) if form == 1 else ()):
+        m = swmhd.ShallowWaterModel(g, G, F, formulation=FORM[form], lorentz_forcing=True, strict=strict, kernel=kern, fuse_halo=False)
+        bufs = []
+        for name, a in zip(m.names, q):
+            f, b = pitched(a); m.solution[name] = f; bufs.append(b)
+        for k in range(4):
+            m.Gn[k], b = pitched(); bufs.append(b)
+        assert m.fields[0].stride_y == pitch
+        m.calculate_tendencies(); torch.cuda.synchronize()
+        for w, gf in zip(want, m.Gn):
+            got = gf.data.cpu().numpy()
+            if strict:
+                assert np.array_equal(w[I], got[I])
+            else:
+                assert np.abs(w[I] - got[I]).max() <= 1e-12 * np.abs(w[I]).max(), kern
+        for b in bufs:
+            assert torch.all(b[:, W:] == -9.5), "kernel wrote into the row padding"
+        op = swmhd.lorentz_force_func if form == 1 else swmhd.div_lorentz
+        out = (pitched()[0], pitched()[0])
+        op(g, {"A": m.solution["A"], "h": m.solution["h"]}, out=out, strict=strict, kernel=("march" if kern == "split" else kern))
+        torch.cuda.synchronize()
+        for w, of in zip(opw, out):
+            got = of.data.cpu().numpy()
+            assert np.array_equal(w[I], got[I]) if strict else np.abs(w[I] - got[I]).max() <= 1e-13 * np.abs(w[I]).max()
