@@ -6,7 +6,7 @@ from swmhd_amd import configs
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = configs.config3_bickley()
 g = S.RectilinearGrid(size=(N, N), x=cfg["domain"]["x"], y=cfg["domain"]["y"])
-m = S.ShallowWaterModel(g, formulation="VectorInvariant", kernel=(sys.argv[2] if len(sys.argv) > 2 else "auto"))
+m = S.ShallowWaterModel(g, formulation="VectorInvariant", kernel=(sys.argv[2] if len(sys.argv) > 2 else "auto"), lorentz_forcing=(len(sys.argv) <= 3 or sys.argv[3] != "nolorentz"))
 m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
 for _ in range(3): m.time_step(1e-4)
 m.tendency_events = []
