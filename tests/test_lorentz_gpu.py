@@ -189,3 +189,26 @@ def test_error_codes_on_device_pointers(swmhd):
     with pytest.raises(swmhd._lib.SwmhdError, match="halo"):
         swmhd.div_lorentz(g, {"A": A, "h": h})             # ... but not for the divergence form
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("form", ["jacobian", "divergence"])
+@pytest.mark.parametrize("kernel", ["tile", "march"])
+def test_zero_depth_propagates_non_finite_only_through_its_stencil(swmhd, oracle, form, kernel):
+    """Error behaviour of the reference's forcing functions: none -- a dry cell (h -> 0) just propagates Inf/NaN
+    (SURVEY.md 8(b)).  Same here: no trap, no hang; cells outside the stencil footprint of the dry cell are untouched and still
+    match the oracle; inside it both produce non-finite values (which of Inf / NaN differs: Newton reciprocal vs IEEE divide)."""
+    Nx, Ny, H = 300, 60, 3
+    A, h = Hh.random_case(Nx, Ny, H, H, 5)
+    h[H + 30, H + 150] = 0.0
+    h[H + 30, H + 151] = 0.0      # two neighbours, so that the face-averaged depth of the divergence form vanishes too
+    g, f = _fields(swmhd, Nx, Ny, H, A, h)
+    want = _oracle(oracle, form, A, h, g)
+    got = _run(swmhd, form, g, f, strict=False, kernel=kernel)
+    I = g.interior
+    for w, q in zip(want, got):
+        far = np.ones((Ny, Nx), dtype=bool)
+        far[30 - 4:30 + 5, 150 - 4:151 + 5] = False
+        wi, qi = w[I], q[I]
+        assert np.isfinite(qi[far]).all()
+        assert np.abs(wi[far] - qi[far]).max() <= 1e-13 * np.abs(wi[far]).max()
+        assert (~np.isfinite(qi)).any() and (~np.isfinite(wi)).any()      # both propagate Inf/NaN inside the footprint
