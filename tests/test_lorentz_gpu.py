@@ -205,10 +205,13 @@ def test_zero_depth_propagates_non_finite_only_through_its_stencil(swmhd, oracle
     want = _oracle(oracle, form, A, h, g)
     got = _run(swmhd, form, g, f, strict=False, kernel=kernel)
     I = g.interior
+    bad_hip = bad_oracle = False
     for w, q in zip(want, got):
         far = np.ones((Ny, Nx), dtype=bool)
         far[30 - 4:30 + 5, 150 - 4:151 + 5] = False
         wi, qi = w[I], q[I]
         assert np.isfinite(qi[far]).all()
         assert np.abs(wi[far] - qi[far]).max() <= 1e-13 * np.abs(wi[far]).max()
-        assert (~np.isfinite(qi)).any() and (~np.isfinite(wi)).any()      # both propagate Inf/NaN inside the footprint
+        bad_hip |= bool((~np.isfinite(qi)).any())
+        bad_oracle |= bool((~np.isfinite(wi)).any())
+    assert bad_hip and bad_oracle      # both propagate Inf/NaN inside the footprint (in at least one component)
