@@ -37,6 +37,9 @@ def parse():
     p.add_argument("--dt", type=float, default=1e-4)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     p.add_argument("--backend", default="nccl")
+    p.add_argument("--torch-ring", action="store_true", help="multi-GPU: exchange through torch.distributed p2p instead of the native ring")
+    p.add_argument("--force-ring", action="store_true",
+                   help="N=1 rehearsal of the multi-GPU step: y halos through the RCCL ring exchange (sends to self) + overlap")
     return p.parse_args()
 
 
@@ -44,7 +47,7 @@ def build_model(S, args, rank, world, n, ny_local=None):
     from swmhd_amd import configs
     cfg = configs.config3_bickley() if args.formulation == "VectorInvariant" else configs.config4_two_gaussians()
     y0, y1 = cfg["domain"]["y"]
-    dec = S.SlabDecomposition(n * world, world, rank)
+    dec = S.SlabDecomposition(n * world, world, rank, force_ring=args.force_ring)
     g = dec.local_grid(S.RectilinearGrid, n, x=cfg["domain"]["x"], y=(y0, y0 + (y1 - y0) * world))
     return cfg, dec, g
 
@@ -84,15 +87,17 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_ring:
         import torch.distributed as dist
         kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
+        if "RANK" not in os.environ:   # --force-ring started without a launcher
+            kw.update(init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
         dist.init_process_group(args.backend, **kw)
 
     import swmhd_amd as S
     N = args.n
     cfg, dec, g = build_model(S, args, rank, world, N)
-    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=args.formulation, strict=args.strict, decomp=dec)
+    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=args.formulation, strict=args.strict, decomp=dec, native_ring=not args.torch_ring)
     n1, n2 = m.names[:2]
     if args.formulation == "VectorInvariant":
         m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
@@ -104,7 +109,9 @@ def main():
     m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
-    m.tendency_events = [] if world == 1 else None
+    m.tendency_events = []
+    if m._ring is not None:
+        m.ring_time_launches(3 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         m.time_step(args.dt)
@@ -131,26 +138,31 @@ def main():
                                    else f"{N}x{N} cells per GPU, periodic, Conservative formulation + divergence-form Lorentz forcing, two-Gaussian A (BASELINE config 4 ICs)",
                        "step": "one RK3 time step = 3 x (fused tendency+substep kernel, halo fill of 4 fields)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
-                       "decomposition": f"y-slabs x{world} (ring halo exchange over RCCL, overlapped)" if world > 1 else "single GPU",
+                       "decomposition": f"y-slabs x{world} (ring halo exchange over RCCL, overlapped; " + ("native swmhd_ring driver" if m._ring is not None else "torch.distributed p2p") + ")" if dec.ring else "single GPU",
                        "dt": args.dt, "finite": finite},
         }
-        if m.tendency_events:
-            ms = [a.elapsed_time(b) for a, b in m.tendency_events]
+        launches = [(a.elapsed_time(b), r) for a, b, r in m.tendency_events]
+        if m._ring is not None:
+            launches = m.ring_launch_times()
+        if launches:
+            ms = [t for t, _ in launches]
             kern_ms = float(np.mean(ms))
-            achieved = TEND_BYTES_PER_CELL * cells / (kern_ms * 1e-3) / 1e9
+            kcells = N * float(np.mean([r for _, r in launches]))   # rank 0's launches (slab interior rows when N>1)
+            achieved = TEND_BYTES_PER_CELL * kcells / (kern_ms * 1e-3) / 1e9
             # PMC traffic cannot be collected inside this process; the per-launch figure measured with rocprofv3 --pmc on this
             # same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note) is committed
             # under profiles/ and echoed here when the workload matches
             traffic = None
             tp = os.path.join(ROOT, "profiles", "r01", "tendency_pmc_traffic.json")
-            if os.path.exists(tp) and N == 4096 and args.formulation == "VectorInvariant" and not args.strict:
+            if os.path.exists(tp) and N == 4096 and args.formulation == "VectorInvariant" and not args.strict and not dec.ring:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch_corrected")
             # the launch also performs the fused RK3 substep: besides the 64 B/cell of SURVEY 8(d) it reads G- and writes the
             # new state (96 / 128 / 96 B/cell in stages 1 / 2 / 3); `achieved` stays on the conservative 64 B/cell figure
-            fused_bytes = (96 + 128 + 96) / 3.0 * cells
-            line["roofline"] = {"bound": "hbm", "kernel": "k_tendency_vi_march (fused RHS of u,v,h,A incl. Lorentz force + RK3 substep)",
+            fused_bytes = (96 + 128 + 96) / 3.0 * kcells
+            line["roofline"] = {"bound": "hbm", "kernel": ("k_tendency_vi_march" if args.formulation == "VectorInvariant" else "k_tendency_cons_march")
+                                          + " (fused RHS of the 4 prognostic fields incl. Lorentz force + RK3 substep)",
                                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                "traffic": traffic, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells,
+                                "traffic": traffic, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * kcells,
                                 "avg_launch_ms": kern_ms, "launches_timed": len(ms),
                                 "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                 "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,

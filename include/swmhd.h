@@ -60,7 +60,8 @@ extern "C" {
 #define SWMHD_OK 0
 #define SWMHD_EINVAL 1     /* bad extents / null pointer / bad row range */
 #define SWMHD_EHALO 2      /* halo too small for the operator's stencil  */
-#define SWMHD_ENOTSUP 3    /* valid request this build does not implement */
+#define SWMHD_ENOTSUP 3    /* valid request this build does not implement (or: the RCCL library could not be loaded) */
+#define SWMHD_ECOMM 4      /* RCCL reported an error: swmhd_ring_last_error() has its text */
 
 int swmhd_version(void);
 /* Human-readable text for a return code of any entry point (static storage). */
@@ -215,6 +216,57 @@ int swmhd_step_rk3_f32(float *const *q, float *const *q_alt, float *const *Ga, f
                        int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
                        float g, float f, int formulation, int lorentz, float dt, int nsteps,
                        int flags, int *state_in_alt, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, the domain cut into y-slabs (rank r owns global rows [r*Ny, (r+1)*Ny), all x).
+ * The reference is single-process -- its periodic y boundary is the in-memory halo copy of Oceananigans'
+ * fill_halo_regions! (topology = (Periodic, Periodic, Flat), SWMHD_example.jl:16, divergence_sw_mhd.jl:14); here that
+ * copy becomes a ring of RCCL sends/receives between y-neighbours.  A swmhd_ring owns the RCCL
+ * communicator, a high-priority comm stream and two events.  RCCL is loaded at run time from `rccl_path` (NULL/"" =
+ * "librccl.so.1" from the loader path); a host that already uses RCCL (PyTorch) passes the path of ITS copy so that one
+ * instance serves both.  The 128-byte id from swmhd_ring_unique_id (call on ONE rank) must reach every rank out of band
+ * (MPI_Bcast, torch.distributed.broadcast, a file ...) before swmhd_ring_create, which is collective over the ranks and
+ * binds the communicator to the calling thread's current HIP device.
+ * ---------------------------------------------------------------------------------------------- */
+#define SWMHD_RING_ID_BYTES 128
+typedef struct swmhd_ring swmhd_ring;
+int swmhd_ring_unique_id(const char *rccl_path, void *id128);
+int swmhd_ring_create(swmhd_ring **ring, const char *rccl_path, int nranks, int rank, const void *id128);
+int swmhd_ring_destroy(swmhd_ring *ring);
+const char *swmhd_ring_last_error(const swmhd_ring *ring);
+void *swmhd_ring_comm_stream(const swmhd_ring *ring);   /* the ring's hipStream_t */
+
+/* Fill the south/north halo rows of `nfields` parents from the ring neighbours: per field the Hy northern interior rows
+ * go to the north neighbour's south halo and the Hy southern interior rows to the south neighbour's north halo, full padded
+ * width (fill x halos first: corners travel with the rows).  Zero-copy (rows are contiguous), one grouped RCCL launch,
+ * enqueued on `stream`.  With nranks == 1 every send goes to self: a periodic copy through RCCL. */
+int swmhd_ring_exchange_y_f64(swmhd_ring *ring, double *const *fields, int nfields, int Nx, int Ny, int Hx, int Hy,
+                              int64_t stride_y, void *stream);
+int swmhd_ring_exchange_y_f32(swmhd_ring *ring, float *const *fields, int nfields, int Nx, int Ny, int Hx, int Hy,
+                              int64_t stride_y, void *stream);
+
+/* swmhd_step_rk3 for one slab of the ring: `nsteps` RK3 steps, every launch enqueued by this one call.  Per stage the
+ * interior rows [Hy, Ny-Hy) run on `stream` while the neighbour exchange of the state they read is still in flight on
+ * the ring's comm stream; the two Hy-row boundary strips are queued on the comm stream behind that exchange; then the
+ * x halos of the new state are filled and its exchange is started.
+ *   entry: halos of q current (x and y) -- or the exchange this ring left in flight for exactly this state
+ *   exit : the y exchange of the final state is IN FLIGHT on the comm stream: call swmhd_ring_join(ring, stream) before
+ *          anything but swmhd_ring_step_rk3 reads the y halos (or reuses the buffers) on `stream`
+ * flags must not carry SWMHD_WRAP_X/Y; Ny >= 2*Hy+1.  Other arguments and state_in_alt as swmhd_step_rk3. */
+int swmhd_ring_step_rk3_f64(swmhd_ring *ring, double *const *q, double *const *q_alt, double *const *Ga, double *const *Gb,
+                            int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
+                            double g, double f, int formulation, int lorentz, double dt, int nsteps,
+                            int flags, int *state_in_alt, void *stream);
+int swmhd_ring_step_rk3_f32(swmhd_ring *ring, float *const *q, float *const *q_alt, float *const *Ga, float *const *Gb,
+                            int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
+                            float g, float f, int formulation, int lorentz, float dt, int nsteps,
+                            int flags, int *state_in_alt, void *stream);
+int swmhd_ring_join(swmhd_ring *ring, void *stream);   /* order `stream` behind the exchange in flight (no-op if none) */
+
+/* Measurement hook: record HIP events around the next `max_launches` interior launches of swmhd_ring_step_rk3 (0 = off);
+ * swmhd_ring_launch_times waits for them and returns how many (ms, rows) pairs it wrote. */
+int swmhd_ring_time_launches(swmhd_ring *ring, int max_launches);
+int swmhd_ring_launch_times(swmhd_ring *ring, float *ms, int *rows, int capacity);
 
 /* ------------------------------------------------------------------------------------------------
  * Energy and extrema diagnostics, one pass (the reference computes them every iteration:

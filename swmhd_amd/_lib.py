@@ -67,13 +67,39 @@ def _declare(lib):
         f = getattr(lib, f"swmhd_rk3_substep_{sfx}")
         f.argtypes = [C.POINTER(p), C.POINTER(p), C.POINTER(p), i, i, i, i, i64, ft, ft, ft, i, i, i, p]
         f.restype = i
+        f = getattr(lib, f"swmhd_ring_exchange_y_{sfx}")
+        f.argtypes = [p, C.POINTER(p), i, i, i, i, i, i64, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_ring_step_rk3_{sfx}")
+        f.argtypes = [p] + [C.POINTER(p)] * 4 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, ft, i, i, C.POINTER(i), p]
+        f.restype = i
+    lib.swmhd_ring_unique_id.argtypes = [C.c_char_p, p]
+    lib.swmhd_ring_unique_id.restype = i
+    lib.swmhd_ring_create.argtypes = [C.POINTER(p), C.c_char_p, i, i, p]
+    lib.swmhd_ring_create.restype = i
+    lib.swmhd_ring_destroy.argtypes = [p]
+    lib.swmhd_ring_destroy.restype = i
+    lib.swmhd_ring_last_error.argtypes = [p]
+    lib.swmhd_ring_last_error.restype = C.c_char_p
+    lib.swmhd_ring_comm_stream.argtypes = [p]
+    lib.swmhd_ring_comm_stream.restype = p
+    lib.swmhd_ring_join.argtypes = [p, p]
+    lib.swmhd_ring_join.restype = i
+    lib.swmhd_ring_time_launches.argtypes = [p, i]
+    lib.swmhd_ring_time_launches.restype = i
+    lib.swmhd_ring_launch_times.argtypes = [p, C.POINTER(C.c_float), C.POINTER(i), i]
+    lib.swmhd_ring_launch_times.restype = i
 
 
 # every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
 EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
-        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics")]
+        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
+        "ring_exchange_y", "ring_step_rk3")] + [
+    "swmhd_ring_" + name for name in ("unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
+                                      "launch_times")]
+RING_ID_BYTES = 128
 
 
 def lib():

@@ -1,0 +1,292 @@
+// y-slab ring for the multi-GPU engine: an RCCL communicator, a high-priority comm stream and the native
+// step driver that overlaps the neighbour exchange with the interior rows.
+//
+// The reference is single-process: its periodic y-boundary is Oceananigans' in-memory halo copy (topology =
+// (Periodic, Periodic, Flat), jacobian_formulation/SWMHD_example.jl:16; fill_halo_regions! inside update_state!).  With one
+// process per GPU that copy becomes a ring of ncclSend/ncclRecv between y-neighbours.  Parents are x-fastest, so the Hy edge
+// rows of a field (full padded width, corners included) are ONE contiguous run: every send reads the interior edge rows in
+// place and every receive lands directly in the halo rows -- no pack/unpack kernels, one grouped RCCL launch per exchange.
+//
+// RCCL is bound at run time (dlopen of the path the host passes -- the copy PyTorch already loaded when the host is the
+// Python harness) so that libswmhd.so itself carries no link-time dependency on it; single-GPU users never touch it.
+#include "common.hpp"
+#include "../../include/swmhd.h"
+#include <cstring>
+#include <dlfcn.h>
+#include <new>
+#include <rccl/rccl.h>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+bool load_rccl(const char *path, RcclApi &api, std::string &err) {
+    const char *candidates[] = {path, "librccl.so.1", "librccl.so"};
+    for (const char *c : candidates) {
+        if (!c || !*c) continue;
+        api.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+        err = dlerror();
+    }
+    if (!api.handle) return false;
+#define SW_SYM(field, name)                                                                \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name));           \
+    if (!api.field) { err = std::string("missing symbol ") + name; return false; }
+    SW_SYM(GetUniqueId, "ncclGetUniqueId")
+    SW_SYM(CommInitRank, "ncclCommInitRank")
+    SW_SYM(CommDestroy, "ncclCommDestroy")
+    SW_SYM(GroupStart, "ncclGroupStart")
+    SW_SYM(GroupEnd, "ncclGroupEnd")
+    SW_SYM(Send, "ncclSend")
+    SW_SYM(Recv, "ncclRecv")
+    SW_SYM(GetErrorString, "ncclGetErrorString")
+#undef SW_SYM
+    return true;
+}
+
+}  // namespace
+
+struct swmhd_ring {
+    RcclApi api;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0, south = 0, north = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_comm = nullptr;
+    const void *pending = nullptr;   // first parent of the state whose y-exchange is in flight on comm_stream (NULL: none)
+    std::string err;
+    // optional timing of the interior launches (bench.py's roofline leg)
+    std::vector<hipEvent_t> t0, t1;
+    std::vector<int> trows;
+    size_t tcap = 0;
+};
+
+namespace {
+
+int fail(swmhd_ring *r, const char *what, ncclResult_t rc) {
+    r->err = std::string(what) + ": " + (r->api.GetErrorString ? r->api.GetErrorString(rc) : "rccl error");
+    return SWMHD_ECOMM;
+}
+int hipfail(swmhd_ring *r, const char *what, hipError_t e) {
+    r->err = std::string(what) + ": " + hipGetErrorString(e);
+    return -(int)e;
+}
+
+template <typename T> constexpr ncclDataType_t nccl_type();
+template <> constexpr ncclDataType_t nccl_type<double>() { return ncclFloat64; }
+template <> constexpr ncclDataType_t nccl_type<float>() { return ncclFloat32; }
+
+// One grouped launch: for every field, northern edge rows -> north neighbour's south halo, southern edge rows -> south
+// neighbour's north halo.  Issue order (send_n, recv_s, send_s, recv_n per field) is what makes the 1- and 2-rank rings,
+// where both neighbours are the same peer, pair up correctly: RCCL matches sends and receives of a peer in issue order.
+template <typename T>
+int exchange(swmhd_ring *r, T *const *fields, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy, hipStream_t s) {
+    if (!r || !fields || nf <= 0) return SWMHD_EINVAL;
+    if (Nx <= 0 || Ny < Hy || Hy <= 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    const size_t count = (size_t)Hy * (size_t)sy;   // Hy full rows (the pitch padding of the last row travels too: harmless)
+    ncclResult_t rc = r->api.GroupStart();
+    if (rc != ncclSuccess) return fail(r, "ncclGroupStart", rc);
+    for (int f = 0; f < nf; ++f) {
+        T *p = fields[f];
+        if (!p) { r->api.GroupEnd(); return SWMHD_EINVAL; }
+        T *send_s = p + (size_t)Hy * sy, *send_n = p + (size_t)Ny * sy;
+        T *recv_s = p, *recv_n = p + (size_t)(Ny + Hy) * sy;
+        if ((rc = r->api.Send(send_n, count, nccl_type<T>(), r->north, r->comm, s)) != ncclSuccess) break;
+        if ((rc = r->api.Recv(recv_s, count, nccl_type<T>(), r->south, r->comm, s)) != ncclSuccess) break;
+        if ((rc = r->api.Send(send_s, count, nccl_type<T>(), r->south, r->comm, s)) != ncclSuccess) break;
+        if ((rc = r->api.Recv(recv_n, count, nccl_type<T>(), r->north, r->comm, s)) != ncclSuccess) break;
+    }
+    ncclResult_t rc2 = r->api.GroupEnd();
+    if (rc != ncclSuccess) return fail(r, "ncclSend/ncclRecv", rc);
+    if (rc2 != ncclSuccess) return fail(r, "ncclGroupEnd", rc2);
+    return SWMHD_OK;
+}
+
+template <typename T> struct Api;
+template <> struct Api<double> {
+    static constexpr auto stage = swmhd_tendencies_rk3_f64;
+    static constexpr auto halo = swmhd_fill_halo_periodic_multi_f64;
+};
+template <> struct Api<float> {
+    static constexpr auto stage = swmhd_tendencies_rk3_f32;
+    static constexpr auto halo = swmhd_fill_halo_periodic_multi_f32;
+};
+
+// nsteps RK3 steps of one y-slab.  Per stage (X = current state, Y = the other buffer set):
+//   main stream : rows [Hy, Ny-Hy) of X -> Y          (need no remote data; the exchange of X is still in flight)
+//   comm stream : ... exchange of X ... ; rows [0,Hy) and [Ny-Hy,Ny) of X -> Y     (queued behind the exchange)
+//   main stream : wait(comm) ; x-halo fill of Y ; record ; comm waits ; comm: exchange of Y    (overlaps the next stage)
+// The first stage of the first call finds no exchange in flight and the caller's halos current: it runs all rows at once.
+template <typename T>
+int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny, int Hx, int Hy, int64_t sy,
+              T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, int nsteps, int flags, int *state_in_alt,
+              void *stream) {
+    if (!r || !q || !q_alt || !Ga || !Gb || nsteps < 0) return SWMHD_EINVAL;
+    if (flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) return SWMHD_EINVAL;   // y images belong to the neighbours
+    if (Ny < 2 * Hy + 1) return SWMHD_EINVAL;                          // a slab needs interior rows between its two strips
+    const T gam[3] = {T(8.0 / 15.0), T(5.0 / 12.0), T(3.0 / 4.0)};
+    const T zet[3] = {T(0), T(-17.0 / 60.0), T(-5.0 / 12.0)};
+    hipStream_t s = (hipStream_t)stream, c = r->comm_stream;
+    T *cur[4], *alt[4], *gn[4], *gm[4];
+    for (int f = 0; f < 4; ++f) {
+        if (!q[f] || !q_alt[f] || !Ga[f] || !Gb[f]) return SWMHD_EINVAL;
+        cur[f] = q[f]; alt[f] = q_alt[f]; gn[f] = Ga[f]; gm[f] = Gb[f];
+    }
+    if (r->pending && r->pending != (const void *)cur[0]) {   // an exchange of some other state is in flight: drain it first
+        hipError_t e = hipEventRecord(r->ev_comm, c);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, r->ev_comm, 0);
+        if (e != hipSuccess) return hipfail(r, "join", e);
+        r->pending = nullptr;
+    }
+    int swaps = 0;
+    hipError_t e;
+    for (int n = 0; n < nsteps; ++n)
+        for (int st = 0; st < 3; ++st) {
+            const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
+            const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+            const T *const *pgm = st == 0 ? nullptr : cgm;
+            const int store = st < 2 ? 1 : 0;
+            auto run = [&](int j0, int j1, hipStream_t on) {
+                return Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st],
+                                     zet[st], store, j0, j1, flags, (void *)on);
+            };
+            int rc;
+            const bool split = r->pending != nullptr;
+            const int jb = split ? Hy : 0, je = split ? Ny - Hy : Ny;
+            const bool timed = r->t0.size() < r->tcap;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (timed) {
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return SWMHD_EINVAL;
+                (void)hipEventRecord(a, s);
+            }
+            if ((rc = run(jb, je, s))) return rc;
+            if (timed) { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
+            if (split) {
+                if ((rc = run(0, Hy, c))) return rc;
+                if ((rc = run(Ny - Hy, Ny, c))) return rc;
+                if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return hipfail(r, "record", e);
+                if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return hipfail(r, "wait", e);
+            }
+            for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
+            ++swaps;
+            if ((rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return rc;
+            if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return hipfail(r, "record", e);
+            if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return hipfail(r, "wait", e);
+            if ((rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c))) return rc;
+            r->pending = cur[0];
+        }
+    if (state_in_alt) *state_in_alt = swaps & 1;
+    return SWMHD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swmhd_ring_unique_id(const char *rccl_path, void *id128) {
+    if (!id128) return SWMHD_EINVAL;
+    RcclApi api;
+    std::string err;
+    if (!load_rccl(rccl_path, api, err)) return SWMHD_ENOTSUP;
+    ncclUniqueId id;
+    if (api.GetUniqueId(&id) != ncclSuccess) return SWMHD_ECOMM;
+    static_assert(sizeof(id) == SWMHD_RING_ID_BYTES, "ncclUniqueId size");
+    memcpy(id128, &id, sizeof(id));
+    return SWMHD_OK;   // (the dlopen handle is deliberately kept: the library stays loaded for swmhd_ring_create)
+}
+
+int swmhd_ring_create(swmhd_ring **out, const char *rccl_path, int nranks, int rank, const void *id128) {
+    if (!out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return SWMHD_EINVAL;
+    swmhd_ring *r = new (std::nothrow) swmhd_ring;
+    if (!r) return SWMHD_EINVAL;
+    if (!load_rccl(rccl_path, r->api, r->err)) { delete r; return SWMHD_ENOTSUP; }
+    r->nranks = nranks; r->rank = rank;
+    r->south = (rank + nranks - 1) % nranks;
+    r->north = (rank + 1) % nranks;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    if (r->api.CommInitRank(&r->comm, nranks, id, rank) != ncclSuccess) { delete r; return SWMHD_ECOMM; }
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // hi = numerically lowest = highest priority
+    hipError_t e = hipStreamCreateWithPriority(&r->comm_stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_comm, hipEventDisableTiming);
+    if (e != hipSuccess) { swmhd_ring_destroy(r); return -(int)e; }
+    *out = r;
+    return SWMHD_OK;
+}
+
+int swmhd_ring_destroy(swmhd_ring *r) {
+    if (!r) return SWMHD_OK;
+    if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
+    for (auto ev : r->t0) (void)hipEventDestroy(ev);
+    for (auto ev : r->t1) (void)hipEventDestroy(ev);
+    if (r->comm) r->api.CommDestroy(r->comm);
+    if (r->ev_main) (void)hipEventDestroy(r->ev_main);
+    if (r->ev_comm) (void)hipEventDestroy(r->ev_comm);
+    if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
+    delete r;
+    return SWMHD_OK;
+}
+
+const char *swmhd_ring_last_error(const swmhd_ring *r) { return r ? r->err.c_str() : "null ring"; }
+
+void *swmhd_ring_comm_stream(const swmhd_ring *r) { return r ? (void *)r->comm_stream : nullptr; }
+
+int swmhd_ring_join(swmhd_ring *r, void *stream) {
+    if (!r) return SWMHD_EINVAL;
+    if (!r->pending) return SWMHD_OK;
+    hipError_t e = hipEventRecord(r->ev_comm, r->comm_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, r->ev_comm, 0);
+    if (e != hipSuccess) return hipfail(r, "join", e);
+    r->pending = nullptr;
+    return SWMHD_OK;
+}
+
+int swmhd_ring_time_launches(swmhd_ring *r, int max_launches) {
+    if (!r || max_launches < 0) return SWMHD_EINVAL;
+    for (auto ev : r->t0) (void)hipEventDestroy(ev);
+    for (auto ev : r->t1) (void)hipEventDestroy(ev);
+    r->t0.clear(); r->t1.clear(); r->trows.clear();
+    r->tcap = (size_t)max_launches;
+    return SWMHD_OK;
+}
+
+int swmhd_ring_launch_times(swmhd_ring *r, float *ms, int *rows, int capacity) {
+    if (!r || !ms || !rows) return -1;
+    int n = 0;
+    for (size_t i = 0; i < r->t0.size() && n < capacity; ++i) {
+        if (hipEventSynchronize(r->t1[i]) != hipSuccess) break;
+        if (hipEventElapsedTime(&ms[n], r->t0[i], r->t1[i]) != hipSuccess) break;
+        rows[n++] = r->trows[i];
+    }
+    return n;
+}
+
+#define SWMHD_DEF_RING(sfx, T)                                                                                                   \
+    int swmhd_ring_exchange_y_##sfx(swmhd_ring *r, T *const *fields, int nfields, int Nx, int Ny, int Hx, int Hy, int64_t sy,    \
+                                    void *stream) {                                                                              \
+        return exchange<T>(r, fields, nfields, Nx, Ny, Hx, Hy, sy, (hipStream_t)stream);                                         \
+    }                                                                                                                            \
+    int swmhd_ring_step_rk3_##sfx(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny,       \
+                                  int Hx, int Hy, int64_t sy, T dx, T dy, T g, T f, int formulation, int lorentz, T dt,          \
+                                  int nsteps, int flags, int *state_in_alt, void *stream) {                                      \
+        return ring_step<T>(r, q, q_alt, Ga, Gb, Nx, Ny, Hx, Hy, sy, dx, dy, g, f, formulation, lorentz, dt, nsteps, flags,      \
+                            state_in_alt, stream);                                                                               \
+    }
+
+SWMHD_DEF_RING(f64, double)
+SWMHD_DEF_RING(f32, float)
+
+}  // extern "C"

@@ -16,7 +16,7 @@ import torch.distributed as dist
 class SlabDecomposition:
     """Pure bookkeeping: which rows does this rank own, who are its ring neighbours."""
 
-    def __init__(self, Ny_global, world_size=1, rank=0):
+    def __init__(self, Ny_global, world_size=1, rank=0, force_ring=False):
         if Ny_global % world_size:
             raise ValueError(f"Ny_global={Ny_global} not divisible by world_size={world_size}")
         self.Ny_global, self.world_size, self.rank = Ny_global, world_size, rank
@@ -24,6 +24,9 @@ class SlabDecomposition:
         self.j_offset = rank * self.Ny_local
         self.south = (rank - 1) % world_size   # owns rows below mine  (smaller j)
         self.north = (rank + 1) % world_size   # owns rows above mine
+        # ring: y halos come from the neighbour exchange instead of the local periodic copy.  force_ring keeps the exchange
+        # path on with ONE rank (every send goes to self): the RCCL rehearsal a one-GPU box allows (tools/ring_selftest.py).
+        self.ring = world_size > 1 or force_ring
 
     def local_grid(self, grid_cls, Nx, x, y, halo=(3, 3), topology=("Periodic", "Periodic", "Flat")):
         return grid_cls(size=(Nx, self.Ny_local), x=x, y=y, halo=halo, topology=topology,
@@ -34,7 +37,7 @@ def exchange_y_halos(parents, Ny, Hy, decomp, group=None):
     """Fill the south/north halo rows of every parent tensor in `parents` (shape (Ny+2Hy, W), contiguous) from the ring
     neighbours.  x halos must already be filled (corners travel with the rows).  world_size 1: local periodic copy.
     Returns after the exchange has been *enqueued* for CUDA/NCCL tensors (stream-ordered) or completed for CPU/gloo."""
-    if decomp.world_size == 1:
+    if not decomp.ring:
         for p in parents:
             p[:Hy].copy_(p[Ny:Ny + Hy])
             p[Ny + Hy:].copy_(p[Hy:2 * Hy])

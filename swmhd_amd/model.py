@@ -23,7 +23,7 @@ RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True, fused=True, kernel="auto", fuse_halo=True):
+                 overlap=True, fused=True, kernel="auto", fuse_halo=True, native_ring=True):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -45,20 +45,80 @@ class ShallowWaterModel:
         self._wrap = 0
         # Only where the tile kernel runs anyway (small grids): the marching kernels keep the separate 5-us halo launch.
         if fused and fuse_halo and grid.Nx >= grid.Hx and grid.Ny >= grid.Hy and grid.Nx * grid.Ny <= 300000 and kernel in (None, "auto", "tile"):
-            self._wrap = _lib.WRAP_X | (_lib.WRAP_Y if (decomp is None or decomp.world_size == 1) else 0)
+            self._wrap = _lib.WRAP_X | (_lib.WRAP_Y if (decomp is None or not decomp.ring) else 0)
         self._alt = {n: mk(l) for n, l in zip(self.names, locs)} if fused else None
         self.Gn = [mk(l) for l in locs]     # Gⁿ
         self.Gm = [mk(l) for l in locs]     # G⁻
         self.sfx = _SFX[dtype]
         self.clock_time, self.iteration = 0.0, 0
-        self._comm_stream = torch.cuda.Stream() if (self.decomp.world_size > 1 and torch.cuda.is_available()) else None
+        self._comm_stream = torch.cuda.Stream() if (self.decomp.ring and torch.cuda.is_available()) else None
         self._L = _lib.lib()
         self.tendency_events = None   # bench.py: list collecting (start, end) HIP events around every tendency launch
         if any(not f.data.is_cuda for f in self.solution.values()):
             raise _lib.SwmhdError("ShallowWaterModel runs on the GPU only (no CPU fallback)")
+        # y-slab ring: the native RCCL ring (swmhd_ring_*) when the process group is RCCL; torch.distributed p2p otherwise
+        # (gloo rehearsals).  The ring's step driver needs the fused stage kernel and a slab taller than its two strips.
+        self._ring = None
+        if self.decomp.ring and native_ring and fused and grid.Ny > 2 * grid.Hy:
+            self._ring = self._create_ring()
+
+    def _create_ring(self):
+        import ctypes, os
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+            return None
+        dev = self.fields[0].data.device
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy torch has loaded
+        rccl = rccl.encode() if os.path.exists(rccl) else None
+        ident = torch.zeros(_lib.RING_ID_BYTES, dtype=torch.uint8)
+        if self.decomp.rank == 0:
+            buf = (ctypes.c_ubyte * _lib.RING_ID_BYTES)()
+            _lib.check(self._L.swmhd_ring_unique_id(rccl, buf), "swmhd_ring_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(dev)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(ident, src=src, group=self.group)
+        raw = bytes(ident.cpu().tolist())
+        ring = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            rc = self._L.swmhd_ring_create(ctypes.byref(ring), rccl, self.decomp.world_size, self.decomp.rank,
+                                           (ctypes.c_ubyte * _lib.RING_ID_BYTES).from_buffer_copy(raw))
+        _lib.check(rc, "swmhd_ring_create")
+        return ring
+
+    def _ring_check(self, rc, what):
+        if rc == 4:   # SWMHD_ECOMM
+            raise _lib.SwmhdError(f"{what}: {self._L.swmhd_ring_last_error(self._ring).decode()}")
+        _lib.check(rc, what)
+
+    def ring_time_launches(self, n):
+        """bench.py: have the native ring driver record HIP events around its next n interior launches."""
+        self._ring_check(self._L.swmhd_ring_time_launches(self._ring, n), "swmhd_ring_time_launches")
+
+    def ring_launch_times(self, capacity=4096):
+        import ctypes
+        ms, rows = (ctypes.c_float * capacity)(), (ctypes.c_int * capacity)()
+        n = self._L.swmhd_ring_launch_times(self._ring, ms, rows, capacity)
+        return [(ms[k], rows[k]) for k in range(max(n, 0))]
+
+    def _join(self):
+        """Order the current stream behind whatever halo exchange is still in flight."""
+        if self._ring is not None:
+            self._ring_check(self._L.swmhd_ring_join(self._ring, _stream_ptr()), "swmhd_ring_join")
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def __del__(self):
+        ring, self._ring = getattr(self, "_ring", None), None
+        if ring is not None:
+            try:
+                self._L.swmhd_ring_destroy(ring)
+            except Exception:
+                pass
 
     # --- set!(model, u=..., v=..., h=..., A=...) ---------------------------------------------------------------
     def set(self, **kw):
+        self._join()
         for k, v in kw.items():
             self.solution[k].set(v)
         self.update_state()
@@ -72,13 +132,20 @@ class ShallowWaterModel:
     def _fill_x(self, stream=None):
         g = self.grid
         ptrs = _lib.ptr_array([f.ptr for f in self.fields])
-        which = _lib.HALO_X | (_lib.HALO_Y if self.decomp.world_size == 1 else 0)
+        which = _lib.HALO_X | (0 if self.decomp.ring else _lib.HALO_Y)
         f = getattr(self._L, f"swmhd_fill_halo_periodic_multi_{self.sfx}")
         _lib.check(f(ptrs, 4, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, which, _stream_ptr(stream)), "fill_halo_multi")
 
     def update_state(self):
+        self._join()
         self._fill_x()
-        if self.decomp.world_size > 1:
+        if self._ring is not None:
+            g = self.grid
+            f = getattr(self._L, f"swmhd_ring_exchange_y_{self.sfx}")
+            rc = f(self._ring, _lib.ptr_array([q.ptr for q in self.fields]), 4, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y,
+                   _stream_ptr())
+            self._ring_check(rc, "swmhd_ring_exchange_y")
+        elif self.decomp.ring:
             exchange_y_halos([f.data for f in self.fields], self.grid.Ny, self.grid.Hy, self.decomp, self.group)
 
     # --- calculate_tendencies! ------------------------------------------------------------------------------
@@ -88,7 +155,7 @@ class ShallowWaterModel:
             e0.record()
             self._calculate_tendencies(rows, stream)
             e1.record()
-            self.tendency_events.append((e0, e1))
+            self.tendency_events.append((e0, e1, self.grid.Ny))
         else:
             self._calculate_tendencies(rows, stream)
 
@@ -122,7 +189,7 @@ class ShallowWaterModel:
         Gn = _lib.ptr_array([f.ptr for f in self.Gn])
         Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
         f = getattr(self._L, f"swmhd_tendencies_rk3_{self.sfx}")
-        timed = self.tendency_events is not None and rows is None
+        timed = self.tendency_events is not None and 2 * (j1 - j0) > g.Ny    # whole grid, or the interior launch of a slab
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -131,13 +198,34 @@ class ShallowWaterModel:
                self._flags | self._wrap, _stream_ptr())
         if timed:
             e1.record()
-            self.tendency_events.append((e0, e1))
+            self.tendency_events.append((e0, e1, j1 - j0))
         _lib.check(rc, "swmhd_tendencies_rk3")
 
     # --- time_step!(model, dt): RungeKutta3 ------------------------------------------------------------------
+    def _ring_steps(self, dt, n):
+        """n RK3 steps of this slab through the native ring driver (swmhd_ring_step_rk3_*): one C call enqueues every launch."""
+        import ctypes
+        gr = self.grid
+        swapped = ctypes.c_int(0)
+        q = _lib.ptr_array([f.ptr for f in self.fields])
+        qa = _lib.ptr_array([self._alt[nm].ptr for nm in self.names])
+        Ga = _lib.ptr_array([f.ptr for f in self.Gn])
+        Gb = _lib.ptr_array([f.ptr for f in self.Gm])
+        f = getattr(self._L, f"swmhd_ring_step_rk3_{self.sfx}")
+        rc = f(self._ring, q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self.fields[0].stride_y, gr.dx, gr.dy, self.g, self.f,
+               self.form_code, self.lorentz_code, dt, n, self._flags, ctypes.byref(swapped), _stream_ptr())
+        self._ring_check(rc, "swmhd_ring_step_rk3")
+        if swapped.value:
+            self.solution, self._alt = self._alt, self.solution
+            self.Gn, self.Gm = self.Gm, self.Gn
+        self.clock_time += n * dt
+        self.iteration += n
+
     def time_step(self, dt):
+        if self._ring is not None:
+            return self._ring_steps(dt, 1)
         g, H = self.grid, self.grid.Hy
-        multi = self.decomp.world_size > 1
+        multi = self.decomp.ring
         overlap = multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H
         for stage in range(3):
             # one RK3 stage over a row range: either the fused kernel or tendencies followed (later) by the substep
@@ -175,7 +263,7 @@ class ShallowWaterModel:
     def capture_graph(self, dt):
         """Capture TWO RK3 steps (6 fused stages + 6 halo fills) into one HIP graph; two, because the ping-ponged state and the
         G-/Gn pointers return to their original roles after an even number of stages.  `time_steps` then replays it."""
-        if self.decomp.world_size != 1 or not self.fused:
+        if self.decomp.ring or not self.fused:
             raise _lib.SwmhdError("capture_graph: single-GPU fused path only (halo exchange is not capturable)")
         keep = [f.data.clone() for f in self.fields] + [f.data.clone() for f in self.Gm]
         t0, i0 = self.clock_time, self.iteration
@@ -203,7 +291,9 @@ class ShallowWaterModel:
                 self.clock_time += 2 * dt
                 self.iteration += 2
             n = n % 2
-        if n > 0 and self.decomp.world_size == 1 and self.fused and self.tendency_events is None:
+        if n > 0 and self._ring is not None:
+            return self._ring_steps(dt, n)
+        if n > 0 and not self.decomp.ring and self.fused and self.tendency_events is None:
             gr = self.grid
             import ctypes
             swapped = ctypes.c_int(0)
@@ -229,6 +319,7 @@ class ShallowWaterModel:
         """dict(kinetic_energy, magnetic_energy, potential_energy, total_energy, max_abs_u, max_abs_v, max_abs_A, min_h)
         over the whole (possibly decomposed) domain; energies as the reference's mean(...)*Lx*Ly."""
         g = self.grid
+        self._join()
         if not hasattr(self, "_diag_ws"):
             self._diag_ws = torch.empty(_lib.DIAG_WORKSPACE, dtype=torch.float64, device=self.fields[0].data.device)
             self._diag_out = torch.empty(_lib.DIAG_NOUT, dtype=torch.float64, device=self.fields[0].data.device)
@@ -261,6 +352,7 @@ class ShallowWaterModel:
 
     def load_checkpoint(self, path):
         import numpy as np
+        self._join()
         z = np.load(path, allow_pickle=False)
         for n, f in zip(self.names, self.fields):
             f.data.copy_(torch.from_numpy(z[n]).to(f.data.dtype))
@@ -270,6 +362,5 @@ class ShallowWaterModel:
         return self
 
     def synchronize(self):
-        if self._comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._join()
         torch.cuda.synchronize()

@@ -15,6 +15,6 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(20): m.time_step(1e-4)
 e1.record(); torch.cuda.synchronize()
-ms = [a.elapsed_time(b) * 1e3 for a, b in m.tendency_events]
+ms = [a.elapsed_time(b) * 1e3 for a, b, _ in m.tendency_events]
 print("stage medians us:", [round(statistics.median(ms[s::3]), 1) for s in range(3)], " step ms:", round(e0.elapsed_time(e1) / 20, 3),
       " Mcell-steps/s:", round(N * N / (e0.elapsed_time(e1) / 20) / 1e3))
