@@ -188,6 +188,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)
+    m.close()
     if dist:
         dist.destroy_process_group()
 

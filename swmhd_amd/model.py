@@ -84,6 +84,7 @@ class ShallowWaterModel:
             rc = self._L.swmhd_ring_create(ctypes.byref(ring), rccl, self.decomp.world_size, self.decomp.rank,
                                            (ctypes.c_ubyte * _lib.RING_ID_BYTES).from_buffer_copy(raw))
         _lib.check(rc, "swmhd_ring_create")
+        self._comm_stream = None      # the ring owns the comm stream of the native path
         return ring
 
     def _ring_check(self, rc, what):
@@ -108,13 +109,18 @@ class ShallowWaterModel:
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
 
-    def __del__(self):
+    def close(self):
+        """Release the ring (RCCL communicator, comm stream).  Collective over the ranks like its creation; call it before
+        torch.distributed.destroy_process_group()."""
         ring, self._ring = getattr(self, "_ring", None), None
         if ring is not None:
-            try:
-                self._L.swmhd_ring_destroy(ring)
-            except Exception:
-                pass
+            self._L.swmhd_ring_destroy(ring)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # --- set!(model, u=..., v=..., h=..., A=...) ---------------------------------------------------------------
     def set(self, **kw):
