@@ -47,6 +47,28 @@ def main():
     with open(os.path.join(HERE, "convergence_table.json"), "w") as f:
         json.dump(table, f, indent=1)
 
+    # (4) model path (A9 + forcing), 48x40 periodic, both formulations as the reference configures them
+    #     (SWMHD_example.jl:21-33: VectorInvariant + Jacobian force; divergence_sw_mhd.jl:19-31: Conservative + divergence
+    #     force): tendencies of the initial state and the state after two RK3 steps.  PARITY UNPINNED for A9 (the oracle's
+    #     base RHS restates Oceananigans from its published scheme); the fixture guards the restatement against drift.
+    import test_model_oracle as M
+    Nx, Ny, H, dt = 48, 40, 3, 2e-3
+    dx, dy = M.Lx / Nx, M.Ly / Ny
+    xc, xf = (np.arange(-H, Nx + H) + 0.5) * dx, np.arange(-H, Nx + H) * dx
+    yc, yf = (np.arange(-H, Ny + H) + 0.5) * dy, np.arange(-H, Ny + H) * dy
+    cc, fc, cf = np.meshgrid(xc, yc), np.meshgrid(xf, yc), np.meshgrid(xc, yf)
+    out = dict(Nx=Nx, Ny=Ny, H=H, dx=dx, dy=dy, dt=dt)
+    for form, lor, tag in ((1, 1, "vi"), (0, 2, "cons")):
+        h, A = M.hf(*cc), M.Af(*cc)
+        q1, q2 = (M.uf(*fc), M.vf(*cf)) if form == 1 else (M.hf(*fc) * M.uf(*fc), M.hf(*cf) * M.vf(*cf))
+        q = [O.fill_halo_periodic(np.ascontiguousarray(a), Nx, Ny, H, H) for a in (q1, q2, h, A)]
+        G = O.tendencies(*q, Nx, Ny, H, H, dx, dy, form, lor)
+        s = [a.copy() for a in q]
+        for _ in range(2):
+            O.time_step(*s, Nx, Ny, H, H, dx, dy, dt, form, lor)
+        out.update({f"{tag}_q": np.stack(q), f"{tag}_G": np.stack(G), f"{tag}_after2": np.stack(s)})
+    np.savez_compressed(os.path.join(HERE, "model_48x40.npz"), **out)
+
 
 if __name__ == "__main__":
     main()

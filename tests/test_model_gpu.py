@@ -369,3 +369,28 @@ def test_wider_halos_and_pitched_rows(swmhd, oracle, form, lor, halo):
         for w, of in zip(opw, out):
             got = of.data.cpu().numpy()
             assert np.array_equal(w[I], got[I]) if strict else np.abs(w[I] - got[I]).max() <= 1e-13 * np.abs(w[I]).max()
+
+
+@pytest.mark.parametrize("tag,form,lor", [("vi", 1, 1), ("cons", 0, 2)])
+def test_committed_model_fixture(swmhd, tag, form, lor):
+    """tests/golden/model_48x40.npz (restatement-generated, A9 parity unpinned): the HIP engine alone -- no oracle call --
+    reproduces the committed tendencies and the state after two RK3 steps bit for bit (strict) / within tolerance (fast)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_48x40.npz"))
+    Nx, Ny, dx, dy, dt = int(z["Nx"]), int(z["Ny"]), float(z["dx"]), float(z["dy"]), float(z["dt"])
+    q = [np.ascontiguousarray(a) for a in z[f"{tag}_q"]]
+    for strict in (True, False):
+        m = make_model(swmhd, Nx, Ny, form, lor, q, dx, dy, strict=strict)
+        m.calculate_tendencies(); torch.cuda.synchronize()
+        I = m.grid.interior
+        for w, gf in zip(z[f"{tag}_G"], m.Gn):
+            if strict:
+                assert np.array_equal(w[I], gf.numpy()[I])
+            else:
+                assert np.abs(w[I] - gf.numpy()[I]).max() <= 1e-12 * np.abs(w[I]).max()
+        m.time_step(dt); m.time_step(dt); m.synchronize()
+        for w, f in zip(z[f"{tag}_after2"], m.fields):
+            if strict:
+                assert np.array_equal(w, f.numpy())          # halos included
+            else:
+                assert np.abs(w - f.numpy()).max() <= 1e-12 * max(np.abs(w).max(), 1.0)

@@ -149,3 +149,19 @@ def test_reflection_symmetry(oracle, form, lorentz):
     want = [-mf(G0[0][I]), mc(G0[1][I]), mc(G0[2][I]), mc(G0[3][I])]
     for w, g_ in zip(want, Gm):
         assert np.abs(w - g_[I]).max() <= 1e-11 * np.abs(w).max()
+
+
+@pytest.mark.parametrize("tag,form,lor", [("vi", 1, 1), ("cons", 0, 2)])
+def test_committed_model_fixture_reproduces(oracle, tag, form, lor):
+    """tests/golden/model_48x40.npz (restatement-generated; tests/golden/make_golden.py): guards the oracle against drift."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_48x40.npz"))
+    Nx, Ny, H, dx, dy, dt = int(z["Nx"]), int(z["Ny"]), int(z["H"]), float(z["dx"]), float(z["dy"]), float(z["dt"])
+    q = [np.ascontiguousarray(a) for a in z[f"{tag}_q"]]
+    Gt = oracle.tendencies(*q, Nx, Ny, H, H, dx, dy, form, lor, nthreads=4)
+    for w, g in zip(z[f"{tag}_G"], Gt):
+        assert np.array_equal(w, g)
+    for _ in range(2):
+        oracle.time_step(*q, Nx, Ny, H, H, dx, dy, dt, form, lor, nthreads=4)
+    for w, s in zip(z[f"{tag}_after2"], q):
+        assert np.array_equal(w, s)
