@@ -175,12 +175,13 @@ def main():
             out = (S.Field(g), S.Field(g))
             for _ in range(5):
                 op(g, fld, out=out, strict=args.strict)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(30):
-                op(g, fld, out=out, strict=args.strict)
-            e1.record(); torch.cuda.synchronize()
-            op_ms = e0.elapsed_time(e1) / 30
+            evs = []
+            for _ in range(30):     # an event pair around every launch, as for the tendency kernel
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); op(g, fld, out=out, strict=args.strict); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            op_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
             op_bw = 32 * cells / (op_ms * 1e-3) / 1e9
             line["lorentz_operator"] = {"kernel": "k_lorentz_jacobian_march" if args.formulation == "VectorInvariant" else "k_lorentz_divergence_march",
                                         "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -67,6 +67,25 @@ struct Rk3Args {
     T dt, gamma, zeta;
     int first;
 };
+// Wave priority that falls with progress ("laggards first") for the row-marching kernels.  Their grid is ONE round of resident
+// workgroups, so the workgroups sharing a CU start together -- but the SIMD arbiter issues oldest-wave-first, and with equal
+// priorities they finish one after the other: measured for the vector-invariant tendency kernel at 55 %, 75 % and 100 % of the
+// launch (profiles/r01/workgroup_timeline.json), i.e. the last quarter of the launch ran one wave per SIMD, which cannot hide
+// the ~8-cycle dependent-issue latency of fp64 (tools/valu_probe.hip).  Dropping a wave's priority at 60 / 85 / 95 % of its rows
+// lets the others catch up: all workgroups finish within 10 % of each other, launch -6 %.
+struct ProgressPriority {
+    int t1, t2, t3;
+    __device__ __forceinline__ explicit ProgressPriority(int niter)
+        : t1((niter * 3) / 5), t2((niter * 17) / 20), t3((niter * 19) / 20) {
+        __builtin_amdgcn_s_setprio(3);
+    }
+    __device__ __forceinline__ void at(int it) const {
+        if (it == t1) __builtin_amdgcn_s_setprio(2);
+        if (it == t2) __builtin_amdgcn_s_setprio(1);
+        if (it == t3) __builtin_amdgcn_s_setprio(0);
+    }
+};
+
 template <typename T> hipError_t launch_tendency_fast(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
 template <typename T> hipError_t launch_tendency_strict(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
 template <typename T> hipError_t launch_rk3_substep_fast(const Rk3Args<T> &a, hipStream_t s);
