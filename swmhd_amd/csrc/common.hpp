@@ -67,6 +67,29 @@ struct Rk3Args {
     T dt, gamma, zeta;
     int first;
 };
+// Memory operations of the marching kernels are STRAIGHT-LINE code: every iteration issues the same loads and the same stores.
+// Lanes / iterations that own no output (strip-halo lanes, columns beyond Nx, warm-up rows) still issue their stores, with an
+// out-of-range buffer offset that the hardware drops, and loads are made unconditional by clamping.  Reason: the compiler's
+// s_waitcnt insertion assumes, at every control-flow join, the incoming path with the FEWEST operations in flight; with an
+// `if (col_ok)` around the stores (an execz branch) or a `continue` in the warm-up rows the wait for a prefetched row
+// degenerated to vmcnt(0) at the top of every iteration -- each wave also waited for the stores it had just issued and for
+// the row it had prefetched one iteration ago (PF rows of prefetch were in effect none).  With a fixed pattern the exact wait
+// is stated once, at the end of the iteration: only operations OLDER than the row about to enter the windows must be back.
+typedef int sw_v2i __attribute__((ext_vector_type(2)));
+constexpr unsigned SW_OOB = 0xFFFFFFC0u;   // >= any parent's size in bytes (the launcher keeps parents below 4 GiB - 64 B)
+template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(T *parent, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(parent, 0, (int)bytes, 0x00020000);
+}
+template <typename T> __device__ __forceinline__ void buffer_store(T v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    if constexpr (sizeof(T) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sw_v2i, v), r, off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, 0);
+}
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
+template <int N> __device__ __forceinline__ void wait_vmem_all_but() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
+
 // Wave priority that falls with progress ("laggards first") for the row-marching kernels.  Their grid is ONE round of resident
 // workgroups, so the workgroups sharing a CU start together -- but the SIMD arbiter issues oldest-wave-first, and with equal
 // priorities they finish one after the other: measured for the vector-invariant tendency kernel at 55 %, 75 % and 100 % of the
