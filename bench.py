@@ -166,7 +166,7 @@ def main():
                                 "avg_launch_ms": kern_ms, "launches_timed": len(ms),
                                 "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                 "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,
-                                "note": "fp64 WENO5 makes this kernel VALU-bound (~640 fp64 VALU instr/cell-row-lane; see DESIGN.md 4)"}
+                                "note": "fp64 WENO5 makes this kernel VALU-bound: 625 VALU instructions per wave-row put its fp64-VALU floor at ~370 us per launch (DESIGN.md 4.1)"}
         if world == 1:
             # the reference's own hot-path kernel (whole-field Lorentz force, 32 B/cell: read A,h, write Fx,Fy) on the same fields,
             # timed with HIP events outside the step's timed region
