@@ -51,6 +51,8 @@ extern "C" {
 #define SWMHD_WRAP_Y 32       /*   (x images / y images; both = no halo-fill launch at all on a periodic single-GPU grid)           */
 #define SWMHD_SPLIT_KERNEL 8  /* tendency entry points, vector-invariant model: wave-specialised row-marching kernel (A/B)     */
 #define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~2 Mcell up)                       */
+#define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels
+                                 of another stream (the ring's halo exchange and boundary strips) can start while it runs          */
 
 /* topology codes (Oceananigans.Grids.topology) */
 #define SWMHD_PERIODIC 0

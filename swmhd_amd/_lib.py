@@ -13,6 +13,7 @@ TILE_KERNEL = 2
 MARCH_KERNEL = 4
 SPLIT_KERNEL = 8
 WRAP_X, WRAP_Y = 16, 32
+LEAVE_ROOM = 64
 KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4, "split": 8}
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2

@@ -52,6 +52,7 @@ struct TendArgs {
     int fuse, first, store_G;
     int wrap;             // fused periodic halo fill of the NEW state: bit0 = x images, bit1 = y images (0: caller fills halos)
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
+    int leave_room;       // marching kernels: leave ~5 % of the workgroup slots free for another stream's kernels
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;

@@ -157,9 +157,9 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
             const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
             const T *const *pgm = st == 0 ? nullptr : cgm;
             const int store = st < 2 ? 1 : 0;
-            auto run = [&](int j0, int j1, hipStream_t on) {
+            auto run = [&](int j0, int j1, hipStream_t on, int extra = 0) {
                 return Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st],
-                                     zet[st], store, j0, j1, flags, (void *)on);
+                                     zet[st], store, j0, j1, flags | extra, (void *)on);
             };
             int rc;
             const bool split = r->pending != nullptr;
@@ -170,7 +170,8 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
                 if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return SWMHD_EINVAL;
                 (void)hipEventRecord(a, s);
             }
-            if ((rc = run(jb, je, s))) return rc;
+            // (interior rows: leave a few workgroup slots free, or the exchange and the strips could not start before it ends)
+            if ((rc = run(jb, je, s, split ? SWMHD_LEAVE_ROOM : 0))) return rc;
             if (timed) { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
             if (split) {
                 if ((rc = run(0, Hy, c))) return rc;

@@ -75,7 +75,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
-    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_SPLIT_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y)) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_SPLIT_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM)) return SWMHD_EINVAL;
     if ((flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) && (!rk || Hx > Nx || Hy > Ny)) return rk ? SWMHD_EHALO : SWMHD_EINVAL;
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
@@ -92,6 +92,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
     a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
+    a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
     a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : ((flags & SWMHD_SPLIT_KERNEL) ? 3 : 0));
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
     if (rk) {

@@ -185,7 +185,7 @@ class ShallowWaterModel:
                _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
         _lib.check(rc, "swmhd_rk3_substep")
 
-    def _stage_fused(self, dt, stage, rows=None):
+    def _stage_fused(self, dt, stage, rows=None, extra_flags=0):
         """calculate_tendencies! + rk3_substep! in one launch: reads the current state, writes the new state into the
         alternate buffers (swmhd_tendencies_rk3_*)."""
         g = self.grid
@@ -201,7 +201,7 @@ class ShallowWaterModel:
             e0.record()
         rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
                self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
-               self._flags | self._wrap, _stream_ptr())
+               self._flags | self._wrap | extra_flags, _stream_ptr())
         if timed:
             e1.record()
             self.tendency_events.append((e0, e1, j1 - j0))
@@ -235,12 +235,12 @@ class ShallowWaterModel:
         overlap = multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H
         for stage in range(3):
             # one RK3 stage over a row range: either the fused kernel or tendencies followed (later) by the substep
-            run = (lambda rows=None: self._stage_fused(dt, stage, rows)) if self.fused else (lambda rows=None: self.calculate_tendencies(rows=rows))
+            run = (lambda rows=None, fl=0: self._stage_fused(dt, stage, rows, fl)) if self.fused else (lambda rows=None, fl=0: self.calculate_tendencies(rows=rows))
             if overlap and self.iteration + stage > 0:
                 # x halos are current; the y exchange of the previous stage is in flight on the comm stream.  Interior rows run
                 # on the main stream; the two H-row boundary strips are queued on the COMM stream behind the exchange, so they
                 # start the moment the halo rows land and overlap the tail of the interior kernel.
-                run((H, g.Ny - H))
+                run((H, g.Ny - H), _lib.LEAVE_ROOM)    # leave workgroup slots for the comm stream's kernels
                 with torch.cuda.stream(self._comm_stream):
                     run((0, H))
                     run((g.Ny - H, g.Ny))
