@@ -138,7 +138,7 @@ def main():
                                    else f"{N}x{N} cells per GPU, periodic, Conservative formulation + divergence-form Lorentz forcing, two-Gaussian A (BASELINE config 4 ICs)",
                        "step": "one RK3 time step = 3 x (fused tendency+substep kernel, halo fill of 4 fields)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
-                       "decomposition": f"y-slabs x{world} (ring halo exchange over RCCL, overlapped; " + ("native swmhd_ring driver" if m._ring is not None else "torch.distributed p2p") + ")" if dec.ring else "single GPU",
+                       "decomposition": f"y-slabs x{world} (ring halo exchange, backend {args.backend}, overlapped; " + ("native swmhd_ring driver" if m._ring is not None else "torch.distributed p2p") + ")" if dec.ring else "single GPU",
                        "dt": args.dt, "finite": finite},
         }
         launches = [(a.elapsed_time(b), r) for a, b, r in m.tendency_events]
