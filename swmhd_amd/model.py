@@ -73,12 +73,19 @@ class ShallowWaterModel:
         ident = torch.zeros(_lib.RING_ID_BYTES, dtype=torch.uint8)
         if self.decomp.rank == 0:
             buf = (ctypes.c_ubyte * _lib.RING_ID_BYTES)()
-            _lib.check(self._L.swmhd_ring_unique_id(rccl, buf), "swmhd_ring_unique_id")
-            ident = torch.tensor(list(buf), dtype=torch.uint8)
+            rc = self._L.swmhd_ring_unique_id(rccl, buf)
+            if rc == 0:
+                ident = torch.tensor(list(buf), dtype=torch.uint8)
+            else:   # RCCL could not be loaded: every rank learns it from the all-zero id and takes the torch p2p path
+                import sys
+                print(f"swmhd_amd: native ring unavailable ({self._L.swmhd_strerror(rc).decode()}); using torch.distributed p2p",
+                      file=sys.stderr)
         ident = ident.to(dev)
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(ident, src=src, group=self.group)
         raw = bytes(ident.cpu().tolist())
+        if not any(raw):
+            return None
         ring = ctypes.c_void_p()
         with torch.cuda.device(dev):
             rc = self._L.swmhd_ring_create(ctypes.byref(ring), rccl, self.decomp.world_size, self.decomp.rank,
