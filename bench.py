@@ -52,6 +52,20 @@ def build_model(S, args, rank, world, n, ny_local=None):
     return cfg, dec, g
 
 
+def valu_floor(Nx, rows, kern_ms, args):
+    """Secondary bound (SURVEY 8(d) asks for it): the fp64 vector-ALU floor of the vector-invariant marching kernel.  585 VALU
+    instructions per wave per row (static count of the steady loop in the ISA, cross-checked with SQ_INSTS_VALU,
+    profiles/r01/tendency_pmc_sq*.json) x wave-rows / 1024 SIMDs x 2.05 ns per wave-instruction (what one SIMD sustains on fp64,
+    tools/valu_probe.hip)."""
+    if args.formulation != "VectorInvariant" or args.strict:
+        return {}
+    nstrips = -(-Nx // 250)
+    nseg = max(1, (768 // nstrips))
+    wave_rows = nstrips * 4 * (rows + 6 * nseg)
+    floor_ms = 585 * wave_rows / 1024 * 2.05e-6
+    return {"valu_floor_ms": floor_ms, "frac_of_valu_floor": floor_ms / kern_ms}
+
+
 def cpu_baseline(args, cfg):
     """The oracle's RK3 step (C restatement: the reference's per-cell Lorentz functions with their unshared composition +
     the restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 512 x 256 periodic
@@ -166,6 +180,7 @@ def main():
                                 "avg_launch_ms": kern_ms, "launches_timed": len(ms),
                                 "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                 "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,
+                                **valu_floor(N, kcells / N, kern_ms, args),
                                 "note": "fp64 WENO5 makes this kernel VALU-bound: 625 VALU instructions per wave-row put its fp64-VALU floor at ~370 us per launch (DESIGN.md 4.1)"}
         if world == 1:
             # the reference's own hot-path kernel (whole-field Lorentz force, 32 B/cell: read A,h, write Fx,Fy) on the same fields,
