@@ -96,4 +96,39 @@ function diagnostics(q, grid; formulation = VECTOR_INVARIANT, g = 9.81, h_ref = 
     return Array(out)
 end
 
+# ---- several GPUs: one Julia process per GPU (e.g. MPI.jl), the domain cut into y-slabs -----------------------------------
+# The reference is single-process; its periodic y boundary (fill_halo_regions! for (Periodic, Periodic, Flat),
+# SWMHD_example.jl:16) becomes a ring of RCCL sends/receives between y-neighbours (swmhd_ring_*, include/swmhd.h).
+
+"Create this rank's ring.  `bcast!(id::Vector{UInt8}, root)` is any out-of-band broadcast, e.g. `(id, r) -> MPI.Bcast!(id, r, comm)`."
+function ring_create(nranks, rank, bcast!; rccl_path = C_NULL)
+    id = zeros(UInt8, 128)
+    rank == 0 && check(ccall((:swmhd_ring_unique_id, libswmhd), Cint, (Cstring, Ptr{UInt8}), rccl_path, id))
+    bcast!(id, 0)
+    ring = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:swmhd_ring_create, libswmhd), Cint, (Ptr{Ptr{Cvoid}}, Cstring, Cint, Cint, Ptr{UInt8}), ring, rccl_path, nranks, rank, id))
+    return ring[]
+end
+ring_destroy(ring) = check(ccall((:swmhd_ring_destroy, libswmhd), Cint, (Ptr{Cvoid},), ring))
+"Order the current HIP stream behind the halo exchange `ring_steps!` left in flight (before anything else reads the y halos)."
+ring_join(ring) = check(ccall((:swmhd_ring_join, libswmhd), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), ring, hipstream()))
+
+"""
+    ring_steps!(ring, q, q_alt, Ga, Gb, grid, Δt, n; ...) -> state_in_alt::Bool
+
+`native_steps!` for one y-slab of the ring (`grid` is the LOCAL slab grid, halos of `q` filled on entry): the neighbour exchange of
+every stage runs on the ring's stream while the interior rows of the next stage compute.
+"""
+function ring_steps!(ring, q, q_alt, Ga, Gb, grid, Δt, n; formulation = VECTOR_INVARIANT, lorentz = LORENTZ_JACOBIAN, g = 9.81, f = 1.0,
+                     flags = SWMHD_FAST)
+    ptrs(t) = Ptr{Float64}[pp(x) for x in t]
+    swapped = Ref{Cint}(0)
+    check(ccall((:swmhd_ring_step_rk3_f64, libswmhd), Cint,
+                (Ptr{Cvoid}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Cint, Cint, Cint, Cint, Int64,
+                 Float64, Float64, Float64, Float64, Cint, Cint, Float64, Cint, Cint, Ptr{Cint}, Ptr{Cvoid}),
+                ring, ptrs(q), ptrs(q_alt), ptrs(Ga), ptrs(Gb), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]),
+                grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, g, f, formulation, lorentz, Δt, n, flags, swapped, hipstream()))
+    return swapped[] != 0
+end
+
 end # module
