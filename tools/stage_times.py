@@ -8,7 +8,7 @@ cfg = configs.config3_bickley()
 g = S.RectilinearGrid(size=(N, N), x=cfg["domain"]["x"], y=cfg["domain"]["y"])
 m = S.ShallowWaterModel(g, formulation="VectorInvariant", kernel=(sys.argv[2] if len(sys.argv) > 2 else "auto"), lorentz_forcing=(len(sys.argv) <= 3 or sys.argv[3] != "nolorentz"))
 m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
-for _ in range(3): m.time_step(1e-4)
+for _ in range(60): m.time_step(1e-4)   # (device clocks settle after ~30 ms of load)
 m.tendency_events = []
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
