@@ -1,8 +1,8 @@
 import sys, torch
 N=4096
 a=torch.randn(N+6,N+6,dtype=torch.float64,device='cuda'); b=torch.randn_like(a); c=torch.empty_like(a); d=torch.empty_like(a)
-def timeit(fn,n=30):
-    for _ in range(5): fn()
+def timeit(fn,n=100):
+    for _ in range(300): fn()   # (device clocks settle after ~30 ms of load)
     torch.cuda.synchronize()
     e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
     e0.record()

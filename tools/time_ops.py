@@ -10,7 +10,7 @@ A, h = S.Field(g), S.Field(g)
 A.set(cfg["A"]); h.set(lambda X, Y: cfg["h"](X, Y) + 0 * X); A.fill_halo_regions(); h.fill_halo_regions()
 out = (S.Field(g), S.Field(g))
 def timeit(fn, n=30):
-    for _ in range(5): fn()
+    for _ in range(300): fn()   # (device clocks settle after ~30 ms of load)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
