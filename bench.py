@@ -191,7 +191,7 @@ def main():
             op = S.lorentz_force_func if args.formulation == "VectorInvariant" else S.div_lorentz
             fld = {"A": m.solution["A"], "h": m.solution["h"]}
             out = (S.Field(g), S.Field(g))
-            for _ in range(5):
+            for _ in range(300):      # (back to settled clocks after the host-side pause above)
                 op(g, fld, out=out, strict=args.strict)
             evs = []
             for _ in range(30):     # an event pair around every launch, as for the tendency kernel
@@ -204,6 +204,23 @@ def main():
             line["lorentz_operator"] = {"kernel": "k_lorentz_jacobian_march" if args.formulation == "VectorInvariant" else "k_lorentz_divergence_march",
                                         "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": op_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 32 * cells}
+        if world == 1:
+            # the launch SURVEY 8(d)'s 64-B figure describes literally: tendencies only (read 4 fields, write 4 tendencies), no fused
+            # substep -- same kernel template, MODE 4 -- timed like the operator above, outside the step's timed region
+            m.tendency_events = None
+            for _ in range(100):      # (back to settled clocks after the host-side pause above)
+                m.calculate_tendencies()
+            evs = []
+            for _ in range(30):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); m.calculate_tendencies(); e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            t_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+            t_bw = TEND_BYTES_PER_CELL * cells / (t_ms * 1e-3) / 1e9
+            line["tendency_only_launch"] = {"what": "calculate_tendencies! alone (no fused substep): exactly 64 B/cell", "bound": "hbm",
+                                            "avg_launch_ms": t_ms, "achieved": t_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": t_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
         print(json.dumps(line), flush=True)

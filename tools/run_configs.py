@@ -11,7 +11,8 @@ from swmhd_amd import configs
 
 
 def timeit(fn, n):
-    fn(); torch.cuda.synchronize()
+    for _ in range(40): fn()        # (device clocks settle after ~30 ms of load)
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()
