@@ -4,7 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/stream_probe2.hip -o tools/stream_probe2 ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cstdio>
-struct P { const double *r[8]; double *w[8]; };
+struct P { const double *r[12]; double *w[8]; };
 template <int NR, int NW>
 __global__ __launch_bounds__(256, 3) void k(P p, int Nx, int Ny, long sy, int LY, int nstrips) {
     const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
@@ -44,9 +44,10 @@ template <int NR, int NW> void run(P p, int N, long sy) {
 }
 int main() {
     const int N = 4096; const long sy = N + 6; const size_t bytes = (size_t)sy * (N + 6) * 8;
-    P p; double *b[16];
-    for (int i = 0; i < 16; ++i) { hipMalloc(&b[i], bytes); hipMemset(b[i], 0, bytes); }
-    for (int i = 0; i < 8; ++i) { p.r[i] = b[i]; p.w[i] = b[8 + i]; }
-    run<2, 2>(p, N, sy); run<4, 8>(p, N, sy); run<8, 8>(p, N, sy); run<8, 4>(p, N, sy); run<4, 4>(p, N, sy);
+    P p; double *b[20];
+    for (int i = 0; i < 20; ++i) { hipMalloc(&b[i], bytes); hipMemset(b[i], 0, bytes); }
+    for (int i = 0; i < 12; ++i) p.r[i] = b[i];
+    for (int i = 0; i < 8; ++i) p.w[i] = b[12 + i];
+    run<2, 2>(p, N, sy); run<4, 8>(p, N, sy); run<8, 8>(p, N, sy); run<8, 4>(p, N, sy); run<4, 4>(p, N, sy); run<12, 4>(p, N, sy);
     return 0;
 }
