@@ -32,6 +32,37 @@ __global__ __launch_bounds__(256, 3) void k(P p, int Nx, int Ny, long sy, int LY
         for (int f = 0; f < NR; ++f) v[f] = n[f];
     }
 }
+// same pattern with TWO rows of loads in flight
+template <int NR, int NW>
+__global__ __launch_bounds__(256, 3) void k2(P p, int Nx, int Ny, long sy, int LY, int nstrips) {
+    const int strip = blockIdx.x % nstrips, seg = blockIdx.x / nstrips;
+    const int x = strip * 250 + threadIdx.x - 3;
+    const int xc = x < 0 ? 0 : (x >= Nx ? Nx - 1 : x);
+    const bool ok = threadIdx.x >= 3 && threadIdx.x < 253 && x < Nx;
+    const int J0 = seg * LY, J1 = min(J0 + LY, Ny);
+    double v[NR], n1[NR];
+#pragma unroll
+    for (int f = 0; f < NR; ++f) { v[f] = p.r[f][(long)J0 * sy + xc]; n1[f] = p.r[f][(long)min(J0 + 1, Ny - 1) * sy + xc]; }
+    for (int j = J0; j < J1; j += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            double n2[NR];
+            const long on = (long)min(j + u + 2, Ny - 1) * sy + xc;
+#pragma unroll
+            for (int f = 0; f < NR; ++f) n2[f] = p.r[f][on];
+            double s = 0;
+#pragma unroll
+            for (int f = 0; f < NR; ++f) s += v[f];
+            if (ok && j + u < J1) {
+                const long o = (long)(j + u) * sy + x;
+#pragma unroll
+                for (int f = 0; f < NW; ++f) p.w[f][o] = s + f;
+            }
+#pragma unroll
+            for (int f = 0; f < NR; ++f) { v[f] = n1[f]; n1[f] = n2[f]; }
+        }
+    }
+}
 template <int NR, int NW> void run(P p, int N, long sy) {
     const int LY = 92, nstrips = (N + 249) / 250, nseg = (N + LY - 1) / LY;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -40,7 +71,13 @@ template <int NR, int NW> void run(P p, int N, long sy) {
     for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((k<NR, NW>), dim3(nstrips * nseg), dim3(256), 0, 0, p, N, N, sy, LY, nstrips);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 50;
-    printf("%dR %dW (%3d B/cell): %7.1f us  %6.0f GB/s\n", NR, NW, 8 * (NR + NW), ms * 1e3, 8.0 * (NR + NW) * N * N / (ms * 1e-3) / 1e9);
+    printf("%dR %dW (%3d B/cell): %7.1f us  %6.0f GB/s", NR, NW, 8 * (NR + NW), ms * 1e3, 8.0 * (NR + NW) * N * N / (ms * 1e-3) / 1e9);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((k2<NR, NW>), dim3(nstrips * nseg), dim3(256), 0, 0, p, N, N, sy, LY, nstrips);
+    hipEventRecord(e0);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((k2<NR, NW>), dim3(nstrips * nseg), dim3(256), 0, 0, p, N, N, sy, LY, nstrips);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1); ms /= 50;
+    printf("   | two rows in flight: %7.1f us  %6.0f GB/s\n", ms * 1e3, 8.0 * (NR + NW) * N * N / (ms * 1e-3) / 1e9);
 }
 int main() {
     const int N = 4096; const long sy = N + 6; const size_t bytes = (size_t)sy * (N + 6) * 8;
