@@ -50,7 +50,7 @@ extern "C" {
 #define SWMHD_WRAP_X 16       /* swmhd_tendencies_rk3 / swmhd_step_rk3: fuse the periodic halo fill of the NEW state into the kernel */
 #define SWMHD_WRAP_Y 32       /*   (x images / y images; both = no halo-fill launch at all on a periodic single-GPU grid)           */
 #define SWMHD_SPLIT_KERNEL 8  /* tendency entry points, vector-invariant model: wave-specialised row-marching kernel (A/B)     */
-#define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~2 Mcell up)                       */
+#define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~0.3-2 Mcell up, per entry point)  */
 #define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels
                                  of another stream (the ring's halo exchange and boundary strips) can start while it runs          */
 
@@ -183,7 +183,7 @@ int swmhd_rk3_substep_f32(float *const *U, const float *const *Gn, const float *
  * alias q: neighbouring workgroups still read the old state through their halos (ping-pong the two sets).
  * Only the interior of qnew is written (fill its halos before the next stage) unless flags carry SWMHD_WRAP_X / SWMHD_WRAP_Y:
  * then the periodic images of every new value are written into qnew's halo by the same kernel (needs Nx >= Hx, Ny >= Hy;
- * implemented by the LDS-tiled kernel, which these flags therefore select -- meant for grids below ~2 Mcell, where the
+ * implemented by the LDS-tiled kernel, which these flags therefore select -- meant for grids below ~0.3 Mcell, where the
  * saved launches matter).
  * With row ranges (j_begin, j_end) the images are written for the rows computed.  The last stage of a step may pass
  * store_G = 0 (the next step's first stage has zeta = 0 and never reads it).
