@@ -4,9 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import swmhd_amd as S
 from swmhd_amd import configs
-for N in (64, 128, 512, 1024):
+import os
+for N in [int(x) for x in os.environ.get('SIZES', '64,128,512,1024').split(',')]:
     g = S.RectilinearGrid(size=(N, N), x=(-5, 5), y=(-5, 5))
-    for mode in ("eager", "graph"):
+    for mode in ("eager",) if os.environ.get("SIZES") else ("eager", "graph"):
         m = S.ShallowWaterModel(g, formulation="VectorInvariant")
         m.set(u=lambda X, Y: 5 * Y * np.exp(-(X**2 + Y**2)) * 0.01, v=lambda X, Y: -5 * X * np.exp(-(X**2 + Y**2)) * 0.01,
               h=lambda X, Y: np.ones_like(X), A=configs.two_gaussians(0.1))
