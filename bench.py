@@ -96,6 +96,10 @@ def cpu_baseline(args, cfg):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: everything else any library prints there (RCCL announces its version on stdout
+    # when a communicator is created) is sent to stderr.
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -105,7 +109,7 @@ def main():
         import torch.distributed as dist
         kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
         if "RANK" not in os.environ:   # --force-ring started without a launcher
-            kw.update(init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+            kw.update(init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1)
         dist.init_process_group(args.backend, **kw)
 
     import swmhd_amd as S
@@ -223,7 +227,8 @@ def main():
                                             "frac": t_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg)
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     m.close()
     if dist:
         dist.destroy_process_group()
