@@ -1,131 +1,257 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the shallow-water-MHD tendency engine on MI355X.
 
-Contract:  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
-Metric (BASELINE.json): Mcell-steps/sec (fp64) on a 4096^2 periodic grid.  One step = one full RK3 time step of the
-model the reference builds (SWMHD_example.jl:21-42): 3 x {fused tendency evaluation incl. the Jacobian-form Lorentz
-force, RK3 substep of 4 fields, halo fill}.  Workload: BASELINE config 3 (4096x4096, Jacobian formulation = vector-
-invariant u,v,h + tracer A, Bickley-jet-style h/u, fp64), synthetic initial condition resident in HBM before timing.
-Weak scaling for N > 1: every rank owns a 4096 x 4096 y-slab of a 4096 x (4096 N) periodic domain; halo rows move by
-RCCL send/recv between ring neighbours, overlapped with the interior rows on a second stream.
+Contract:  python bench.py --gpus N --steps K --warmup W  prints ONE JSON line (rank 0, stdout).
+Metric (BASELINE.json): Mcell-steps/sec (fp64) on a 4096^2 periodic grid.  One step = one full RK3 time step of the model the
+reference builds (SWMHD_example.jl:21-42): 3 x {fused tendency evaluation incl. the Lorentz force, RK3 substep of 4 fields, halo
+fill}.  Default workload: BASELINE config 3 (4096 x 4096, Jacobian formulation = vector-invariant u,v,h + tracer A, Bickley-jet
+h/u, fp64), synthetic initial condition resident in HBM before timing.
+
+  --config 3|4|5   3: 4096^2 Jacobian (default); 4: 8192^2 divergence formulation; 5: 16384^2 Jacobian (2048 rows per GPU)
+  --scaling weak|strong   N > 1: weak = every rank owns a full per-GPU slab (config 3: 4096 x 4096 per GPU, config 5: 16384 x 2048
+                   per GPU, config 4: 8192 x 1024 per GPU); strong = the fixed global grid cut into N y-slabs (config 3: 4096 x 4096/N,
+                   config 4: 8192 x 8192/N).  Defaults: weak for configs 3 and 5, strong for config 4 (as BASELINE.json words them).
+  N > 1 without a launcher (RANK unset): bench.py starts N worker processes itself (one per GPU) and forwards rank 0's line.
+
+Halo rows move by RCCL send/recv between ring neighbours (native swmhd_ring driver), overlapped with the interior rows on a second
+stream.  Every number in the `roofline` block is derived by the formula printed next to it from a value measured in this run or from
+a file under profiles/ that is named in the block together with the kernel-source hash it was collected at.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 TEND_BYTES_PER_CELL = 64       # read u,v,h,A + write 4 tendencies, fp64
-STEP_BYTES_PER_CELL = 544      # 3*64 + 96 + 128 + 128
+STAGE_BYTES_PER_CELL = (96, 128, 96)   # what the three FUSED stage launches move: + new state; + G- read; last stage stores no G
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+VALU_NS_PER_WAVE_INST = 2.05   # one fp64 wave-instruction per 2.05 ns per SIMD (tools/valu_probe.hip: 4 cycles at ~1.95 GHz under load)
+
+CONFIGS = {
+    3: dict(builder="config3_bickley", Nx=4096, Ny=4096, slab=4096, form="VectorInvariant", default_scaling="weak",
+            text="Bickley-jet h/u + current-sheet A (BASELINE config 3)"),
+    4: dict(builder="config4_two_gaussians", Nx=8192, Ny=8192, slab=1024, form="Conservative", default_scaling="strong",
+            text="two-Gaussian A, h = 1, uh = vh = 0 (BASELINE config 4)"),
+    5: dict(builder="config3_bickley", Nx=16384, Ny=16384, slab=2048, form="VectorInvariant", default_scaling="weak",
+            text="Bickley-jet h/u + current-sheet A at 16384^2 (BASELINE config 5)"),
+}
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=100)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--size", dest="n", type=int, default=4096, help="grid edge per GPU (default: BASELINE config 3)")
-    p.add_argument("--formulation", default="VectorInvariant", choices=["VectorInvariant", "Conservative"])
+    p.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    p.add_argument("--scaling", default=None, choices=["weak", "strong"])
+    p.add_argument("--size", dest="n", type=int, default=None, help="override the grid edge Nx (and Ny) of the configuration")
+    p.add_argument("--formulation", default=None, choices=["VectorInvariant", "Conservative"], help="override the configuration's formulation")
+    p.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     p.add_argument("--strict", action="store_true", help="time the oracle-order (bitwise) kernels instead of the fast ones")
-    p.add_argument("--dt", type=float, default=1e-4)
+    p.add_argument("--dt", type=float, default=None)
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     p.add_argument("--backend", default="nccl")
     p.add_argument("--torch-ring", action="store_true", help="multi-GPU: exchange through torch.distributed p2p instead of the native ring")
     p.add_argument("--force-ring", action="store_true",
                    help="N=1 rehearsal of the multi-GPU step: y halos through the RCCL ring exchange (sends to self) + overlap")
-    return p.parse_args()
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="create the process group, barrier, print {'launcher': 'ok', ...} and exit (tests the launcher without a GPU)")
+    return p.parse_args(argv)
 
 
-def build_model(S, args, rank, world, n, ny_local=None):
+# ------------------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with no torchrun around it
+# ------------------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """Start N fresh worker processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set) BEFORE anything in this process touches the GPU,
+    forward rank 0's stdout (the JSON line), fail if any worker fails.  Never re-execs a GPU-initialised process."""
+    import socket
+    N = args.gpus
+    if args.backend == "nccl":
+        import torch   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < N:
+            print(f"bench.py: --gpus {N} requested but only {have} GPU(s) are visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for p, c in zip(procs, codes):      # a failed rank leaves the others waiting in a collective: stop exactly those processes
+                if c is None:
+                    p.terminate()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    out = procs[0].stdout.read().decode()
+    for p in procs:
+        try:
+            p.wait(timeout=60)
+        except subprocess.TimeoutExpired:
+            p.kill(); p.wait()
+    if rc == 0:
+        sys.stdout.write(out); sys.stdout.flush()
+    else:
+        print(f"bench.py: a worker failed (exit code {rc}); no result line", file=sys.stderr)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# workload
+# ------------------------------------------------------------------------------------------------------------------------------
+def workload(args, world):
+    """(cfg dict, Nx, Ny_global, Ny_local, formulation, scaling, y-domain) of this run."""
     from swmhd_amd import configs
-    cfg = configs.config3_bickley() if args.formulation == "VectorInvariant" else configs.config4_two_gaussians()
+    c = CONFIGS[args.config]
+    cfg = getattr(configs, c["builder"])()
+    form = args.formulation or c["form"]
+    if args.formulation and args.formulation != c["form"]:
+        cfg = configs.config3_bickley() if form == "VectorInvariant" else configs.config4_two_gaussians()
+    scaling = args.scaling or c["default_scaling"]
+    Nx = args.n or c["Nx"]
+    full_Ny = args.n or c["Ny"]                  # the configuration's global grid
+    slab = min(args.n or c["slab"], full_Ny)     # rows per GPU when weak-scaled
     y0, y1 = cfg["domain"]["y"]
-    dec = S.SlabDecomposition(n * world, world, rank, force_ring=args.force_ring)
-    g = dec.local_grid(S.RectilinearGrid, n, x=cfg["domain"]["x"], y=(y0, y0 + (y1 - y0) * world))
-    return cfg, dec, g
+    yc, Ly = 0.5 * (y0 + y1), (y1 - y0)
+    if scaling == "strong":
+        Ny_global = full_Ny
+        ydom = (y0, y1)
+    else:
+        # weak: every GPU owns `slab` rows at the configuration's dy; the N slabs are centred on the configuration's y axis (config 3:
+        # N = 1 is exactly the 4096^2 Bickley domain; configs 4/5 at N = 8 are exactly the 8192^2 / 16384^2 domains)
+        Ny_global = slab * world
+        ext = Ly * Ny_global / full_Ny
+        ydom = (yc - ext / 2, yc + ext / 2)
+    if Ny_global % world:
+        raise SystemExit(f"bench.py: Ny={Ny_global} is not divisible by --gpus {world}")
+    return cfg, Nx, Ny_global, Ny_global // world, form, scaling, ydom
 
 
-def valu_floor(Nx, rows, kern_ms, args):
-    """Secondary bound (SURVEY 8(d) asks for it): the fp64 vector-ALU floor of the vector-invariant marching kernel.  585 VALU
-    instructions per wave per row (static count of the steady loop in the ISA, cross-checked with SQ_INSTS_VALU,
-    profiles/r01/tendency_pmc_sq*.json) x wave-rows / 1024 SIMDs x 2.05 ns per wave-instruction (what one SIMD sustains on fp64,
-    tools/valu_probe.hip)."""
-    if args.formulation != "VectorInvariant" or args.strict:
-        return {}
-    nstrips = -(-Nx // 250)
-    nseg = max(1, (768 // nstrips))
-    wave_rows = nstrips * 4 * (rows + 6 * nseg)
-    floor_ms = 585 * wave_rows / 1024 * 2.05e-6
-    return {"valu_floor_ms": floor_ms, "frac_of_valu_floor": floor_ms / kern_ms}
+def committed(name):
+    """A JSON file under profiles/r02 (or None) plus whether it was collected at the kernel sources that are running now."""
+    from swmhd_amd import _lib
+    path = os.path.join(PROFILE_DIR, name)
+    if not os.path.exists(path):
+        return None, {"file": os.path.relpath(path, ROOT), "status": "absent"}
+    d = json.load(open(path))
+    now = _lib.source_hash()
+    src = {"file": os.path.relpath(path, ROOT), "kernel_source_hash": d.get("kernel_source_hash"), "git_head": d.get("git_head"),
+           "running_kernel_source_hash": now}
+    src["status"] = "current" if d.get("kernel_source_hash") == now else "stale: kernel sources changed since it was collected"
+    return (d if src["status"] == "current" else None), src
 
 
-def cpu_baseline(args, cfg):
-    """The oracle's RK3 step (C restatement: the reference's per-cell Lorentz functions with their unshared composition +
-    the restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 512 x 256 periodic
-    block cut from the centre of the configuration, stepped until the time budget is used."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, cfg, form, dx, dy, dt):
+    """The oracle's RK3 step (C restatement: the reference's per-cell Lorentz functions with their unshared composition + the
+    restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 512 x 256 periodic block at the
+    workload's dx, dy and fields, stepped until the time budget is used -- on all cores of the box's share, then on ONE thread."""
+    import numpy as np
     from oracle import oracle as O
     import swmhd_amd as S
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)   # the box's CPU share for one GPU
     Nx, Ny = 512, 256
-    x0, x1 = cfg["domain"]["x"]; y0, y1 = cfg["domain"]["y"]
-    dx, dy = (x1 - x0) / args.n, (y1 - y0) / args.n
     g = S.RectilinearGrid(size=(Nx, Ny), x=(-Nx * dx / 2, Nx * dx / 2), y=(-Ny * dy / 2, Ny * dy / 2))
-    form = 1 if args.formulation == "VectorInvariant" else 0
+    fcode = 1 if form == "VectorInvariant" else 0
     names = [("u", ("Face", "Center")), ("v", ("Center", "Face")), ("h", ("Center", "Center")), ("A", ("Center", "Center"))]
     q = []
     for nm, loc in names:
         X, Y = g.nodes(loc)
         q.append(O.fill_halo_periodic(np.ascontiguousarray(cfg[nm](X, Y) + 0 * X), Nx, Ny, 3, 3))
-    work = O.time_step(*q, Nx, Ny, 3, 3, dx, dy, args.dt, form, 2 - form, nthreads=cores)   # warm
-    t0 = time.perf_counter(); reps = 0
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        O.time_step(*q, Nx, Ny, 3, 3, dx, dy, args.dt, form, 2 - form, nthreads=cores, work=work); reps += 1
-    dt = time.perf_counter() - t0
-    return {"value": Nx * Ny * reps / dt / 1e6, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{Nx}x{Ny} periodic block at the workload's dx,dy and fields, {reps} RK3 steps; C oracle (reference's "
-                      f"unshared per-cell Lorentz composition + restated Oceananigans RHS), OpenMP over {cores} threads; "
-                      "Julia/Oceananigans are not available on the box"}
+
+    def rate(nthreads, budget):
+        work = O.time_step(*q, Nx, Ny, 3, 3, dx, dy, dt, fcode, 2 - fcode, nthreads=nthreads)   # warm
+        t0 = time.perf_counter(); reps = 0
+        while time.perf_counter() - t0 < budget:
+            O.time_step(*q, Nx, Ny, 3, 3, dx, dy, dt, fcode, 2 - fcode, nthreads=nthreads, work=work); reps += 1
+        return Nx * Ny * reps / (time.perf_counter() - t0) / 1e6, reps
+
+    v_all, reps_all = rate(cores, args.cpu_seconds * 2 / 3)
+    v_one, reps_one = rate(1, args.cpu_seconds / 3)
+    return {"value": v_all, "unit": "Mcell-steps/s", "cores": cores, "kind": "port",
+            "value_1_thread": v_one, "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+            "sample": f"{Nx}x{Ny} periodic block at the workload's dx,dy and fields; {reps_all} RK3 steps on {cores} OpenMP threads, "
+                      f"{reps_one} on 1 thread; C oracle (reference's unshared per-cell Lorentz composition + restated Oceananigans "
+                      "RHS, gcc -O3 -ffp-contract=off); Julia/Oceananigans are not available on the box"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+
     # stdout carries exactly ONE line, the JSON: everything else any library prints there (RCCL announces its version on stdout
     # when a communicator is created) is sent to stderr.
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+
+    import numpy as np
+    import torch
     dist = None
-    if world > 1 or args.force_ring:
+    if world > 1 or args.force_ring or args.rendezvous_only:
         import torch.distributed as dist
-        kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if args.backend == "nccl" else {}
+        kw = {}
+        if args.backend == "nccl":
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+            kw = {"device_id": torch.device("cuda", torch.cuda.current_device())}
         if "RANK" not in os.environ:   # --force-ring started without a launcher
             kw.update(init_method=f"tcp://127.0.0.1:{29500 + os.getpid() % 2000}", rank=0, world_size=1)
         dist.init_process_group(args.backend, **kw)
+    if args.rendezvous_only:
+        dist.barrier()
+        if rank == 0:
+            json_out.write(json.dumps({"launcher": "ok", "n_gpus": world, "backend": args.backend}) + "\n"); json_out.flush()
+        dist.destroy_process_group()
+        return
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
 
     import swmhd_amd as S
-    N = args.n
-    cfg, dec, g = build_model(S, args, rank, world, N)
-    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=args.formulation, strict=args.strict, decomp=dec, native_ring=not args.torch_ring)
+    from swmhd_amd import _lib
+    cfg, Nx, Ny_global, Ny_local, form, scaling, ydom = workload(args, world)
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    dec = S.SlabDecomposition(Ny_global, world, rank, force_ring=args.force_ring)
+    g = dec.local_grid(S.RectilinearGrid, Nx, x=cfg["domain"]["x"], y=ydom)
+    dt = args.dt if args.dt is not None else 0.2 * min(g.dx, g.dy) / 4.2      # CFL 0.2 on sqrt(g h) + U ~ 4.2
+    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=args.strict, decomp=dec, native_ring=not args.torch_ring, dtype=dtype)
     n1, n2 = m.names[:2]
-    if args.formulation == "VectorInvariant":
-        m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
-    else:
-        m.set(**{n1: cfg["u"], n2: cfg["v"], "h": cfg["h"], "A": cfg["A"]})
+    m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
 
     # The device needs ~30 ms of sustained load before its clocks settle (a step measured right after start-up is 6-10 % slower
     # than the same step a hundred steps later): spin the step 40 times before the W warm-up steps the contract counts.
     for _ in range(40 + args.warmup):
-        m.time_step(args.dt)
+        m.time_step(dt)
     m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -134,7 +260,7 @@ def main():
         m.ring_time_launches(3 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        m.time_step(args.dt)
+        m.time_step(dt)
     m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
@@ -146,21 +272,25 @@ def main():
     finite = all(torch.isfinite(f.data).all().item() for f in m.fields)
 
     if rank == 0:
-        cells = N * N
-        value = cells * world * args.steps / wall / 1e6
+        cells_global = Nx * Ny_global
+        value = cells_global * args.steps / wall / 1e6
+        lor = "Jacobian" if form == "VectorInvariant" else "divergence"
+        bpe = 8 if args.dtype == "f64" else 4
         line = {
-            "metric": "Mcell-steps/sec (fp64) on 4096^2 periodic grid", "value": value, "unit": "Mcell-steps/s",
+            "metric": f"Mcell-steps/sec ({'fp64' if bpe == 8 else 'fp32'}) on "
+                      + ("4096^2" if (Nx, Ny_global) == (4096, 4096) else f"{Nx}x{Ny_global}") + " periodic grid",
+            "value": value, "unit": "Mcell-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{N}x{N} cells per GPU, periodic, {args.formulation} formulation + "
-                                   f"{'Jacobian' if args.formulation == 'VectorInvariant' else 'divergence'}-form Lorentz forcing, "
-                                   "Bickley-jet h/u + current-sheet A (BASELINE config 3)" if args.formulation == "VectorInvariant"
-                                   else f"{N}x{N} cells per GPU, periodic, Conservative formulation + divergence-form Lorentz forcing, two-Gaussian A (BASELINE config 4 ICs)",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE config {args.config}: global grid {Nx}x{Ny_global} ({Nx}x{Ny_local} cells per GPU), periodic, "
+                                   f"{form} formulation + {lor}-form Lorentz forcing, {CONFIGS[args.config]['text']}",
                        "step": "one RK3 time step = 3 x (fused tendency+substep kernel, halo fill of 4 fields)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
                        "spin_up": "40 untimed steps before the warm-up steps (device clocks settle after ~30 ms of load)",
-                       "decomposition": f"y-slabs x{world} (ring halo exchange, backend {args.backend}, overlapped; " + ("native swmhd_ring driver" if m._ring is not None else "torch.distributed p2p") + ")" if dec.ring else "single GPU",
-                       "dt": args.dt, "finite": finite},
+                       "decomposition": (f"y-slabs x{world} (ring halo exchange, backend {args.backend}, overlapped; "
+                                         + ("native swmhd_ring driver" if m._ring is not None else "torch.distributed p2p") + ")")
+                                        if dec.ring else "single GPU",
+                       "dt": dt, "finite": finite, "kernel_source_hash": _lib.source_hash()},
         }
         launches = [(a.elapsed_time(b), r) for a, b, r in m.tendency_events]
         if m._ring is not None:
@@ -168,65 +298,97 @@ def main():
         if launches:
             ms = [t for t, _ in launches]
             kern_ms = float(np.mean(ms))
-            kcells = N * float(np.mean([r for _, r in launches]))   # rank 0's launches (slab interior rows when N>1)
-            achieved = TEND_BYTES_PER_CELL * kcells / (kern_ms * 1e-3) / 1e9
-            # PMC traffic cannot be collected inside this process; the per-launch figure measured with rocprofv3 --pmc on this
-            # same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950 note) is committed
-            # under profiles/ and echoed here when the workload matches
-            traffic = None
-            tp = os.path.join(ROOT, "profiles", "r01", "tendency_pmc_traffic.json")
-            if os.path.exists(tp) and N == 4096 and args.formulation == "VectorInvariant" and not args.strict and not dec.ring:
-                traffic = json.load(open(tp)).get("hbm_bytes_per_launch_corrected")
-            # the launch also performs the fused RK3 substep: besides the 64 B/cell of SURVEY 8(d) it reads G- and writes the
-            # new state (96 / 128 / 96 B/cell in stages 1 / 2 / 3); `achieved` stays on the conservative 64 B/cell figure
-            fused_bytes = (96 + 128 + 96) / 3.0 * kcells
-            line["roofline"] = {"bound": "hbm", "kernel": ("k_tendency_vi_march" if args.formulation == "VectorInvariant" else "k_tendency_cons_march")
-                                          + " (fused RHS of the 4 prognostic fields incl. Lorentz force + RK3 substep)",
-                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                "traffic": traffic, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * kcells,
-                                "avg_launch_ms": kern_ms, "launches_timed": len(ms),
-                                "fused_substep_bytes_per_launch": fused_bytes, "achieved_incl_fused_substep": fused_bytes / (kern_ms * 1e-3) / 1e9,
-                                "whole_step_GBps_on_544B": STEP_BYTES_PER_CELL * cells * args.steps / wall / 1e9,
-                                **valu_floor(N, kcells / N, kern_ms, args),
-                                "note": "fp64 WENO5 makes this kernel VALU-bound: 625 VALU instructions per wave-row put its fp64-VALU floor at ~370 us per launch (DESIGN.md 4.1)"}
-        if world == 1:
-            # the reference's own hot-path kernel (whole-field Lorentz force, 32 B/cell: read A,h, write Fx,Fy) on the same fields,
-            # timed with HIP events outside the step's timed region
-            op = S.lorentz_force_func if args.formulation == "VectorInvariant" else S.div_lorentz
+            krows = float(np.mean([r for _, r in launches]))      # rank 0's launches (slab interior rows when N > 1)
+            kcells = Nx * krows
+            tend_bytes = TEND_BYTES_PER_CELL * bpe // 8
+            achieved = tend_bytes * kcells / (kern_ms * 1e-3) / 1e9
+            fused_bytes = sum(STAGE_BYTES_PER_CELL) / 3.0 * bpe / 8 * kcells
+            kname = "k_tendency_vi_march" if form == "VectorInvariant" else "k_tendency_cons_march"
+            roof = {"bound": "hbm", "kernel": kname + " (fused RHS of the 4 prognostic fields incl. Lorentz force + RK3 substep)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "formula": f"achieved = {tend_bytes} B/cell (SURVEY 8(d): 4 fields read + 4 tendencies written) x cells_per_launch / avg_launch_ms",
+                    "algorithmic_bytes_per_launch": tend_bytes * kcells, "cells_per_launch": kcells,
+                    "avg_launch_ms": kern_ms, "launches_timed": len(ms),
+                    "timing": "HIP events around every stage launch inside the timed region, on the launch stream",
+                    "fused_stage": {"bytes_per_cell_stage_1_2_3": [b * bpe // 8 for b in STAGE_BYTES_PER_CELL],
+                                    "mean_bytes_per_launch": fused_bytes, "achieved": fused_bytes / (kern_ms * 1e-3) / 1e9,
+                                    "frac": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "what": "bytes the fused stage launches really move (new state written, G- read in stages 2-3, no G "
+                                            "store in stage 3); `achieved` above stays on the 64-B tendency figure"},
+                    "whole_step_GBps_on_320B": sum(STAGE_BYTES_PER_CELL) * bpe / 8 * cells_global * args.steps / wall / 1e9}
+            # HBM traffic from the PMC counters cannot be collected inside this process: the per-launch figure measured with
+            # rocprofv3 --pmc on this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950
+            # note of the microarchitecture guide) lives under profiles/ and is echoed ONLY while the kernel sources are unchanged.
+            default_workload = (args.config == 3 and world == 1 and not args.strict and not dec.ring and args.n is None
+                                and args.formulation is None and bpe == 8)
+            tr, tsrc = committed("tendency_pmc_traffic.json")
+            roof["traffic"] = tr.get("hbm_bytes_per_launch_corrected") if (tr and default_workload) else None
+            roof["traffic_source"] = tsrc if default_workload else {"status": "not collected for this workload"}
+            ks, ksrc = committed("fullstep_kernel_stats.json")
+            if ks and default_workload:
+                roof["rocprof_avg_launch_ms"] = ks.get("tendency_stage_mean_ms")
+                roof["rocprof_source"] = ksrc
+            # secondary bound (SURVEY 8(d) asks for it): the fp64 vector-ALU floor of the marching kernel =
+            # VALU instructions per wave-row (PMC SQ_INSTS_VALU / wave-rows, committed) x wave-rows / SIMDs x ns per instruction
+            geo = _lib.tendency_launch_geometry(Nx, int(round(krows)), 1 if form == "VectorInvariant" else 0, bpe,
+                                                _lib.LEAVE_ROOM if dec.ring else 0)
+            roof["launch_geometry"] = geo
+            vp, vsrc = committed("tendency_pmc_valu.json")
+            if geo["kind"] == 2 and not args.strict:
+                waves = geo["threads"] // 64
+                wave_rows = geo["nstrips"] * waves * krows
+                valu = {"source": vsrc, "wave_rows_per_launch": wave_rows, "simds": geo["cus"] * 4,
+                        "ns_per_wave_instruction_per_simd": VALU_NS_PER_WAVE_INST,
+                        "formula": "floor_ms = valu_insts_per_wave_row x wave_rows_per_launch / simds x ns_per_wave_instruction"}
+                if vp and default_workload:
+                    ipr = vp["valu_insts_per_wave_row"]
+                    floor_ms = ipr * wave_rows / (geo["cus"] * 4) * VALU_NS_PER_WAVE_INST * 1e-6
+                    valu.update({"valu_insts_per_wave_row": ipr, "floor_ms": floor_ms, "frac_of_floor": floor_ms / kern_ms})
+                    stream_ms = fused_bytes / 5.1e12 * 1e3     # tools/stream_probe2.hip: what this access pattern streams at
+                    roof["binding_bound"] = "fp64-valu" if floor_ms >= stream_ms else "hbm-streaming"
+                    roof["binding_bound_note"] = (f"VALU floor {floor_ms:.3f} ms vs streaming floor {stream_ms:.3f} ms for the fused-stage bytes "
+                                                  "at the 5.1 TB/s this row-marching access pattern reaches; the 64-B HBM figure would need "
+                                                  f"{tend_bytes * kcells / 8e12 * 1e3:.3f} ms")
+                roof["valu"] = valu
+            line["roofline"] = roof
+
+        def timed_launches(fn, n_spin, K):
+            """K back-to-back launches inside ONE event pair (settled clocks: n_spin launches first)."""
+            for _ in range(n_spin):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(K):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / K
+
+        if world == 1 and not dec.ring:
+            cells = Nx * Ny_local
+            ks, ksrc = committed("operators_kernel_stats.json")
+            # the reference's own hot-path kernel (whole-field Lorentz force, 32 B/cell fp64: read A,h, write Fx,Fy) on the same fields
+            op = S.lorentz_force_func if form == "VectorInvariant" else S.div_lorentz
             fld = {"A": m.solution["A"], "h": m.solution["h"]}
-            out = (S.Field(g), S.Field(g))
-            for _ in range(300):      # (back to settled clocks after the host-side pause above)
-                op(g, fld, out=out, strict=args.strict)
-            evs = []
-            for _ in range(30):     # an event pair around every launch, as for the tendency kernel
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); op(g, fld, out=out, strict=args.strict); e1.record()
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            op_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-            op_bw = 32 * cells / (op_ms * 1e-3) / 1e9
-            line["lorentz_operator"] = {"kernel": "k_lorentz_jacobian_march" if args.formulation == "VectorInvariant" else "k_lorentz_divergence_march",
-                                        "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                        "frac": op_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": 32 * cells}
-        if world == 1:
-            # the launch SURVEY 8(d)'s 64-B figure describes literally: tendencies only (read 4 fields, write 4 tendencies), no fused
-            # substep -- same kernel template, MODE 4 -- timed like the operator above, outside the step's timed region
+            out = (S.Field(g, dtype=dtype), S.Field(g, dtype=dtype))
+            op_ms = timed_launches(lambda: op(g, fld, out=out, strict=args.strict), 300, 50)
+            op_bytes = 4 * bpe * cells
+            opk = "k_lorentz_jacobian_march" if form == "VectorInvariant" else "k_lorentz_divergence_march"
+            line["lorentz_operator"] = {"kernel": opk, "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bytes / (op_ms * 1e-3) / 1e9,
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "algorithmic_bytes_per_launch": op_bytes, "timing": "50 back-to-back launches inside one HIP event pair",
+                                        "rocprof_avg_launch_ms": (ks or {}).get(opk + "_mean_ms") if default_workload else None,
+                                        "rocprof_source": ksrc if default_workload else None}
+            # the launch SURVEY 8(d)'s 64-B figure describes literally: tendencies only (no fused substep), same kernel template
             m.tendency_events = None
-            for _ in range(100):      # (back to settled clocks after the host-side pause above)
-                m.calculate_tendencies()
-            evs = []
-            for _ in range(30):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); m.calculate_tendencies(); e1.record()
-                evs.append((e0, e1))
-            torch.cuda.synchronize()
-            t_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-            t_bw = TEND_BYTES_PER_CELL * cells / (t_ms * 1e-3) / 1e9
-            line["tendency_only_launch"] = {"what": "calculate_tendencies! alone (no fused substep): exactly 64 B/cell", "bound": "hbm",
-                                            "avg_launch_ms": t_ms, "achieved": t_bw, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": t_bw / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": TEND_BYTES_PER_CELL * cells}
+            t_ms = timed_launches(m.calculate_tendencies, 100, 50)
+            t_bytes = TEND_BYTES_PER_CELL * bpe // 8 * cells
+            line["tendency_only_launch"] = {"what": "calculate_tendencies! alone (no fused substep): exactly the 64 B/cell of SURVEY 8(d)",
+                                            "bound": "hbm", "avg_launch_ms": t_ms, "achieved": t_bytes / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                            "unit": "GB/s", "frac": t_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "algorithmic_bytes_per_launch": t_bytes, "timing": "50 back-to-back launches inside one HIP event pair"}
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args, cfg)
+            line["cpu_baseline"] = cpu_baseline(args, cfg, form, g.dx, g.dy, dt)
         json_out.write(json.dumps(line) + "\n")
         json_out.flush()
     m.close()

@@ -43,16 +43,16 @@ extern "C" {
 
 #define SWMHD_VERSION 100
 
-/* flags */
+/* flags (bit mask) */
 #define SWMHD_FAST 0
-#define SWMHD_STRICT 1
-#define SWMHD_TILE_KERNEL 2   /* force the LDS-tiled kernel   (default: chosen by size -- tiles for small grids / thin strips, */
-#define SWMHD_WRAP_X 16       /* swmhd_tendencies_rk3 / swmhd_step_rk3: fuse the periodic halo fill of the NEW state into the kernel */
-#define SWMHD_WRAP_Y 32       /*   (x images / y images; both = no halo-fill launch at all on a periodic single-GPU grid)           */
-#define SWMHD_SPLIT_KERNEL 8  /* tendency entry points, vector-invariant model: wave-specialised row-marching kernel (A/B)     */
-#define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel            row-marching from ~0.3-2 Mcell up, per entry point)  */
-#define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels
-                                 of another stream (the ring's halo exchange and boundary strips) can start while it runs          */
+#define SWMHD_STRICT 1        /* oracle operation order, IEEE divides, no FMA contraction (bit parity); see above                      */
+#define SWMHD_TILE_KERNEL 2   /* force the LDS-tiled kernel.  Default (neither bit): chosen by size -- tiles for small grids and thin  */
+#define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel.   strips, row-marching from ~0.3-2 Mcell up (per entry point)          */
+                              /* (8 is unassigned: it selected an experimental kernel that was removed)                               */
+#define SWMHD_WRAP_X 16       /* swmhd_tendencies_rk3 / swmhd_step_rk3: fuse the periodic halo fill of the NEW state into the kernel   */
+#define SWMHD_WRAP_Y 32       /*   (x images / y images; both = no halo-fill launch at all on a periodic single-GPU grid)              */
+#define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels of
+                                 another stream (the ring's halo exchange and boundary strips) can start while it runs                */
 
 /* topology codes (Oceananigans.Grids.topology) */
 #define SWMHD_PERIODIC 0
@@ -218,6 +218,13 @@ int swmhd_step_rk3_f32(float *const *q, float *const *q_alt, float *const *Ga, f
                        int Nx, int Ny, int Hx, int Hy, int64_t stride_y, float dx, float dy,
                        float g, float f, int formulation, int lorentz, float dt, int nsteps,
                        int flags, int *state_in_alt, void *stream);
+
+/* Launch geometry the fast tendency entry points use for an Nx x rows launch on the current device (introspection for
+ * benchmarks: bench.py derives the kernel's fp64-VALU floor from it; nothing in the reference corresponds to it).
+ * out[0] = kernel kind (1 LDS-tiled, 2 row-marching), out[1] = threads per workgroup, out[2] = strips (workgroups along x),
+ * out[3] = segments (workgroups along y), out[4] = rows per segment, out[5] = resident workgroups per CU the kernel is built
+ * for, out[6] = halo lanes per strip side, out[7] = compute units of the device.  elem_size 8 (f64) or 4 (f32); flags as above. */
+int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int flags, int out[8]);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, the domain cut into y-slabs (rank r owns global rows [r*Ny, (r+1)*Ny), all x).

@@ -11,10 +11,9 @@ STRICT = 1
 FAST = 0
 TILE_KERNEL = 2
 MARCH_KERNEL = 4
-SPLIT_KERNEL = 8
 WRAP_X, WRAP_Y = 16, 32
 LEAVE_ROOM = 64
-KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4, "split": 8}
+KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4}
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
 DIAG_NOUT, DIAG_WORKSPACE = 7, 1024 * 7
@@ -74,6 +73,8 @@ def _declare(lib):
         f = getattr(lib, f"swmhd_ring_step_rk3_{sfx}")
         f.argtypes = [p] + [C.POINTER(p)] * 4 + [i, i, i, i, i64, ft, ft, ft, ft, i, i, ft, i, i, C.POINTER(i), p]
         f.restype = i
+    lib.swmhd_tendency_launch_geometry.argtypes = [i, i, i, i, i, C.POINTER(i)]
+    lib.swmhd_tendency_launch_geometry.restype = i
     lib.swmhd_ring_unique_id.argtypes = [C.c_char_p, p]
     lib.swmhd_ring_unique_id.restype = i
     lib.swmhd_ring_create.argtypes = [C.POINTER(p), C.c_char_p, i, i, p]
@@ -93,7 +94,7 @@ def _declare(lib):
 
 
 # every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
-EXPORTS = ["swmhd_version", "swmhd_strerror"] + [
+EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
         "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
@@ -114,6 +115,26 @@ def lib():
         _LIB = C.CDLL(LIB_PATH)
         _declare(_LIB)
     return _LIB
+
+
+def tendency_launch_geometry(Nx, rows, formulation, elem_size=8, flags=0):
+    """dict(kind, threads, nstrips, nseg, rows_per_segment, wg_per_cu, halo_lanes, cus) of the fast tendency launch (swmhd.h)."""
+    out = (C.c_int * 8)()
+    check(lib().swmhd_tendency_launch_geometry(Nx, rows, formulation, elem_size, flags, out), "swmhd_tendency_launch_geometry")
+    keys = ("kind", "threads", "nstrips", "nseg", "rows_per_segment", "wg_per_cu", "halo_lanes", "cus")
+    return dict(zip(keys, list(out)))
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources libswmhd.so is built from: profiles/ files record it, so that bench.py
+    can tell whether a committed counter value still describes the kernels that are running."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.hpp"))
+                    + [os.path.join(src, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def check(rc, what=""):

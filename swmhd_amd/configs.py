@@ -51,3 +51,40 @@ def config4_two_gaussians(L=10.0):
         v=lambda X, Y: np.zeros_like(X),
         A=two_gaussians(0.5),
     )
+
+
+def config5_bickley_slab(Lx=2 * np.pi, Ly=20.0, nslabs=8):
+    """16384^2 Jacobian formulation weak-scaled over 8 GPUs: the 16384 x 2048 slab of config 3's Bickley jet that contains the jet
+    axis (y in [-Ly/16, Ly/16]), run as its own y-periodic domain on one GPU (BASELINE config 5; fp32-vs-fp64 sweep)."""
+    c = config3_bickley(Lx, Ly)
+    c["domain"] = dict(x=(-Lx / 2, Lx / 2), y=(-Ly / (2 * nslabs), Ly / (2 * nslabs)))
+    return c
+
+
+def config4_slab(L=10.0, nslabs=8):
+    """8192^2 divergence formulation over 8 GPUs: the 8192 x 1024 slab that holds the two Gaussians (y in [-L/16, L/16]) as its
+    own y-periodic domain (BASELINE config 4 at per-GPU size)."""
+    c = config4_two_gaussians(L)
+    c["domain"] = dict(x=(-L / 2, L / 2), y=(-L / (2 * nslabs), L / (2 * nslabs)))
+    return c
+
+
+# name -> (config builder, Nx, Ny, formulation) of every single-GPU workload BASELINE.json names (SURVEY.md 8(d))
+WORKLOADS = {
+    "config2": (config2_uniform_bx, 1024, 1024, "Conservative"),
+    "config3": (config3_bickley, 4096, 4096, "VectorInvariant"),
+    "config4_slab": (config4_slab, 8192, 1024, "Conservative"),
+    "config5_slab": (config5_bickley_slab, 16384, 2048, "VectorInvariant"),
+}
+
+
+def build_model(S, name, dtype=None, strict=False, kernel="auto", **kw):
+    """ShallowWaterModel + grid for one of WORKLOADS, initial condition set and halos filled."""
+    import torch
+    mk, Nx, Ny, form = WORKLOADS[name]
+    cfg = mk()
+    g = S.RectilinearGrid(size=(Nx, Ny), x=cfg["domain"]["x"], y=cfg["domain"]["y"])
+    m = S.ShallowWaterModel(g, G, F, formulation=form, dtype=dtype or torch.float64, strict=strict, kernel=kernel, **kw)
+    n1, n2 = m.names[:2]
+    m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
+    return m, g, cfg

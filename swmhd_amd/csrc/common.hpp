@@ -110,7 +110,66 @@ struct ProgressPriority {
     }
 };
 
+// ---- launch geometry of the row-marching kernels --------------------------------------------------------------------------
+// One workgroup = a strip of nt - 2*xh output columns x LY rows; the grid is a whole number of rounds of resident workgroups.
+struct MarchGeometry {
+    int nt;        // threads per workgroup (strip width incl. 2*xh halo lanes)
+    int nstrips, nseg, LY;
+    int wg_per_cu; // resident workgroups per CU the kernel is built for
+};
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount; 256 on MI355X), cached per process.
+inline int device_cu_count() {
+    static int cus = 0;
+    if (cus <= 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+// Tuning knobs are read from the environment ONCE per process (not on every launch).
+inline int env_knob(const char *name, int &cache) {   // cache: 0 = not read yet, -1 = unset, > 0 = value
+    if (cache == 0) {
+        const char *e = getenv(name);
+        const int v = e ? atoi(e) : 0;
+        cache = v > 0 ? v : -1;
+    }
+    return cache > 0 ? cache : 0;
+}
+// Strip width: among the candidate workgroup sizes take the one whose strips cover Nx with the fewest lanes (4096 columns:
+// 17 strips x 256 lanes = 4352, but 11 x 384 = 4224); ties go to 256.  Rows per segment: the smallest whole number of rounds
+// of resident workgroups (wg_per_cu x CUs slots; ~5 % fewer with leave_room, so that another stream's kernels find room) whose
+// segments are at most 128 rows, but never shorter than ly_min rows.
+inline MarchGeometry march_geometry(int Nx, int rows, int xh, const int *nts, const int *wgs, int ncand, int ly_min, bool leave_room,
+                                    int force_nt, int force_ly) {
+    MarchGeometry g{};
+    long best = -1;
+    for (int k = 0; k < ncand; ++k) {
+        const int txo = nts[k] - 2 * xh, ns = (Nx + txo - 1) / txo;
+        const long lanes = (long)ns * nts[k];
+        const bool take = force_nt ? nts[k] == force_nt : (best < 0 || lanes < best || (lanes == best && nts[k] == 256));
+        if (take) { best = lanes; g.nt = nts[k]; g.nstrips = ns; g.wg_per_cu = wgs[k]; }
+    }
+    if (best < 0) { g.nt = nts[0]; g.nstrips = (Nx + nts[0] - 2 * xh - 1) / (nts[0] - 2 * xh); g.wg_per_cu = wgs[0]; }
+    int slots = device_cu_count() * g.wg_per_cu;
+    if (leave_room) slots -= (slots * 3) / 64;
+    int LY = 32;
+    for (int k = 1; k <= 64; ++k) {
+        const int ns = (slots * k) / g.nstrips;
+        if (ns < 1) continue;
+        const int ly = (rows + ns - 1) / ns;
+        if (ly <= 128) { LY = ly < ly_min ? ly_min : ly; break; }
+    }
+    if (force_ly > 0) LY = force_ly;
+    g.LY = LY;
+    g.nseg = (rows + LY - 1) / LY;
+    return g;
+}
+
 template <typename T> hipError_t launch_tendency_fast(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
+// geometry the fast tendency launcher would use (kind: 1 = LDS-tiled kernel, 2 = row-marching kernel); for bench.py's VALU floor
+int tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int kernel_variant, int leave_room, int wrap, int out[8]);
 template <typename T> hipError_t launch_tendency_strict(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
 template <typename T> hipError_t launch_rk3_substep_fast(const Rk3Args<T> &a, hipStream_t s);
 template <typename T> hipError_t launch_rk3_substep_strict(const Rk3Args<T> &a, hipStream_t s);

@@ -151,6 +151,15 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
     }
     int swaps = 0;
     hipError_t e;
+    // Error exit from the middle of a step: whatever was enqueued stays enqueued, so order the caller's stream behind the comm
+    // stream and forget the in-flight exchange -- `pending` must never describe an exchange that was not (fully) issued -- and
+    // tell the caller which buffer set holds the newest completed stage.
+    auto bail = [&](int code) {
+        if (hipEventRecord(r->ev_comm, c) == hipSuccess) (void)hipStreamWaitEvent(s, r->ev_comm, 0);
+        r->pending = nullptr;
+        if (state_in_alt) *state_in_alt = swaps & 1;
+        return code;
+    };
     for (int n = 0; n < nsteps; ++n)
         for (int st = 0; st < 3; ++st) {
             const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
@@ -167,24 +176,30 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
             const bool timed = r->t0.size() < r->tcap;
             hipEvent_t a = nullptr, b = nullptr;
             if (timed) {
-                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return SWMHD_EINVAL;
+                if ((e = hipEventCreate(&a)) != hipSuccess) return bail(hipfail(r, "hipEventCreate", e));
+                if ((e = hipEventCreate(&b)) != hipSuccess) { (void)hipEventDestroy(a); return bail(hipfail(r, "hipEventCreate", e)); }
                 (void)hipEventRecord(a, s);
             }
             // (interior rows: leave a few workgroup slots free, or the exchange and the strips could not start before it ends)
-            if ((rc = run(jb, je, s, split ? SWMHD_LEAVE_ROOM : 0))) return rc;
-            if (timed) { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
+            rc = run(jb, je, s, split ? SWMHD_LEAVE_ROOM : 0);
+            if (timed) {
+                if (rc) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+                else { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
+            }
+            if (rc) return bail(rc);
             if (split) {
-                if ((rc = run(0, Hy, c))) return rc;
-                if ((rc = run(Ny - Hy, Ny, c))) return rc;
-                if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return hipfail(r, "record", e);
-                if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return hipfail(r, "wait", e);
+                if ((rc = run(0, Hy, c))) return bail(rc);
+                if ((rc = run(Ny - Hy, Ny, c))) return bail(rc);
+                if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return bail(hipfail(r, "record", e));
+                if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
             }
             for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
             ++swaps;
-            if ((rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return rc;
-            if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return hipfail(r, "record", e);
-            if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return hipfail(r, "wait", e);
-            if ((rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c))) return rc;
+            r->pending = nullptr;   // the exchange of the OLD state has been consumed; none of the new state is in flight yet
+            if ((rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return bail(rc);
+            if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return bail(hipfail(r, "record", e));
+            if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
+            if ((rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c))) return bail(rc);
             r->pending = cur[0];
         }
     if (state_in_alt) *state_in_alt = swaps & 1;

@@ -75,7 +75,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
-    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_SPLIT_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM)) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM)) return SWMHD_EINVAL;
     if ((flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) && (!rk || Hx > Nx || Hy > Ny)) return rk ? SWMHD_EHALO : SWMHD_EINVAL;
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
@@ -93,7 +93,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
-    a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : ((flags & SWMHD_SPLIT_KERNEL) ? 3 : 0));
+    a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : 0);
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
     if (rk) {
         a.fuse = 1; a.first = rk->Gm ? 0 : 1; a.store_G = rk->store_G; a.dt = rk->dt; a.gamma = rk->gamma; a.zeta = rk->zeta;
@@ -191,9 +191,18 @@ const char *swmhd_strerror(int rc) {
         case SWMHD_OK: return "success";
         case SWMHD_EINVAL: return "invalid argument (null pointer, bad extents, stride, spacing, row range or flags)";
         case SWMHD_EHALO: return "halo too small for the operator's stencil (Jacobian form needs 2, divergence form 3)";
-        case SWMHD_ENOTSUP: return "not supported by this build";
+        case SWMHD_ENOTSUP: return "not supported by this build (or: the RCCL library could not be loaded)";
+        case SWMHD_ECOMM: return "RCCL reported an error (swmhd_ring_last_error has its text)";
         default: return rc < 0 ? hipGetErrorString((hipError_t)(-rc)) : "unknown swmhd error";
     }
+}
+
+int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int flags, int out[8]) {
+    if (!out || Nx <= 0 || rows <= 0 || (elem_size != 4 && elem_size != 8)) return SWMHD_EINVAL;
+    if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
+    const int variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : 0);
+    return tendency_launch_geometry(Nx, rows, formulation, elem_size, (flags & SWMHD_STRICT) ? 1 : variant, (flags & SWMHD_LEAVE_ROOM) ? 1 : 0,
+                                    (flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) ? 1 : 0, out);
 }
 
 #define SWMHD_DEF_LORENTZ(sfx, T)                                                                                      \

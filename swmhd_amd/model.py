@@ -289,24 +289,40 @@ class ShallowWaterModel:
         with torch.cuda.graph(self._graph):
             self.time_step(dt); self.time_step(dt)
         self._graph_dt = dt
+        # the graph has the device pointers of THIS role assignment baked in (state in `solution`, scratch in `_alt`, Gn/Gm as
+        # they are now): it may only be replayed while the roles are the same, i.e. after an even number of eager steps
+        self._graph_roles = self._roles()
         for f, k in zip(self.fields + self.Gm, keep):   # capture does not execute; undo the two warm-up steps
             f.data.copy_(k)
         self.clock_time, self.iteration = t0, i0
         return self
 
+    def _roles(self):
+        """Which buffer plays which role right now (every RK3 step swaps state<->scratch and Gn<->G- an odd number of times)."""
+        return tuple(f.ptr for f in self.fields) + tuple(f.ptr for f in self.Gn)
+
     def time_steps(self, n, dt):
         """n RK3 steps: graph replays (2 steps each) when a graph was captured for this dt; otherwise the native step driver
         (swmhd_step_rk3_*: one C call enqueues all 6n launches) on a single GPU, or Python-driven stages on several."""
         g = getattr(self, "_graph", None)
-        if g is not None and self._graph_dt == dt and self.iteration > 0:
+        if g is not None and self._graph_dt == dt and n >= 2 and self._roles() != self._graph_roles:
+            # an odd number of steps has run since capture (a leftover step of an earlier call, or a plain time_step): the
+            # graph would read the scratch buffers as the state.  One eager step restores the captured roles.
+            self._driver_steps(dt, 1)
+            n -= 1
+        if g is not None and self._graph_dt == dt and self._roles() == self._graph_roles:
             for _ in range(n // 2):
                 g.replay()
                 self.clock_time += 2 * dt
                 self.iteration += 2
             n = n % 2
-        if n > 0 and self._ring is not None:
+        if n > 0:
+            self._driver_steps(dt, n)
+
+    def _driver_steps(self, dt, n):
+        if self._ring is not None:
             return self._ring_steps(dt, n)
-        if n > 0 and not self.decomp.ring and self.fused and self.tendency_events is None:
+        if not self.decomp.ring and self.fused and self.tendency_events is None:
             gr = self.grid
             import ctypes
             swapped = ctypes.c_int(0)

@@ -25,7 +25,11 @@ def rccl_world_of_one():
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
     torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
+    import socket
+    with socket.socket() as sk:      # a free port, not a fixed one (another job on the box may hold it)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     yield dist
     torch.cuda.synchronize()
