@@ -137,10 +137,10 @@ inline int env_knob(const char *name, int &cache) {   // cache: 0 = not read yet
     }
     return cache > 0 ? cache : 0;
 }
-// Strip width: among the candidate workgroup sizes take the one whose strips cover Nx with the fewest lanes (4096 columns:
-// 17 strips x 256 lanes = 4352, but 11 x 384 = 4224); ties go to 256.  Rows per segment: the smallest whole number of rounds
-// of resident workgroups (wg_per_cu x CUs slots; ~5 % fewer with leave_room, so that another stream's kernels find room) whose
-// segments are at most 128 rows, but never shorter than ly_min rows.
+// Strip width: the FIRST candidate workgroup size unless a later one covers Nx with at least 5 % fewer lanes (1024 columns: 5 strips x
+// 256 lanes = 1280, but 9 x 128 = 1152).  Rows per segment: the smallest whole number of rounds of resident workgroups
+// (wg_per_cu x CUs slots; ~5 % fewer with leave_room, so that another stream's kernels find room) whose segments are at most
+// 128 rows, but never shorter than ly_min rows.
 inline MarchGeometry march_geometry(int Nx, int rows, int xh, const int *nts, const int *wgs, int ncand, int ly_min, bool leave_room,
                                     int force_nt, int force_ly) {
     MarchGeometry g{};
@@ -148,7 +148,7 @@ inline MarchGeometry march_geometry(int Nx, int rows, int xh, const int *nts, co
     for (int k = 0; k < ncand; ++k) {
         const int txo = nts[k] - 2 * xh, ns = (Nx + txo - 1) / txo;
         const long lanes = (long)ns * nts[k];
-        const bool take = force_nt ? nts[k] == force_nt : (best < 0 || lanes < best || (lanes == best && nts[k] == 256));
+        const bool take = force_nt ? nts[k] == force_nt : (best < 0 || lanes * 20 <= best * 19);
         if (take) { best = lanes; g.nt = nts[k]; g.nstrips = ns; g.wg_per_cu = wgs[k]; }
     }
     if (best < 0) { g.nt = nts[0]; g.nstrips = (Nx + nts[0] - 2 * xh - 1) / (nts[0] - 2 * xh); g.wg_per_cu = wgs[0]; }

@@ -8,7 +8,8 @@ C-ABI) against the CPU oracle on all host threads -- once on the initial conditi
 (configs 2 and 4 start from rest, so only the later state exercises the momentum fluxes).
 
 Tolerance (stated, asserted, and the achieved error is recorded in gpurun_out/fullsize_parity.json):
-    max|G_hip - G_oracle| <= TOL * max(max|G|, S),   TOL = 1e-13 (fp64 operators), 1e-12 (fp64 fused tendencies), 1e-4 (fp32)
+    max|G_hip - G_oracle| <= TOL * max(max|G|, S),   TOL = 1e-13 (fp64), 2e-5 (fp32 operators), 1e-4 (fp32 tendencies)
+(achieved on MI355X, profiles/r02/fullsize_parity.json: <= 5e-15 in fp64, <= 5e-7 in fp32, relative to max(max|G|, S))
 S is the magnitude of the largest TERM summed into the tendency (flux / dx, g h / dx, ...): rounding errors scale with the terms,
 not with their sum, and at these resolutions the sum is often orders of magnitude smaller than its terms (config 3: the mass
 fluxes u h / dx are ~650 while G_h = -div(u h) is ~3e-4, so one ulp of a flux is 2e-10 of max|G_h| in fp64 and 0.15 in fp32 -- the
@@ -102,14 +103,14 @@ def test_fast_kernels_match_oracle_at_baseline_size(swmhd, oracle, name, dtype):
         got = [f.numpy() for f in m.Gn]
         wantG = O.tendencies(*q, g.Nx, g.Ny, 3, 3, g.dx, g.dy, fcode, lcode, G, F, nthreads=NTHREADS)
         compare(f"{name}/{sfx}/{phase}/tendencies", list(m.names), got, wantG, term_scales(form, q, g.dx, g.dy, fmax),
-                1e-12 if f64 else 1e-4, I)
+                1e-13 if f64 else 1e-4, I)
         del got, wantG, want
 
 
 def test_config5_precision_sweep_at_slab_size(swmhd):
     """BASELINE config 5: fp32 vs fp64 from identical fp64 initial conditions at the 16384 x 2048 slab -- max|F32 - F64| after one
     RHS evaluation (relative to max(max|G|, term scale): the fp32 run also rounds its INPUTS, so cancelling terms lose
-    eps32 * |term|) and of the state after 10 and 100 RK3 steps (relative to max|state|)."""
+    eps32 * |term|) and of the state after 10 and 100 RK3 steps (relative to max|state|; u and v relative to the common velocity scale max(|u|, |v|))."""
     from swmhd_amd import configs
     S = swmhd
     ms = {}
@@ -135,9 +136,12 @@ def test_config5_precision_sweep_at_slab_size(swmhd):
             m.synchronize()
         done = nsteps
         r = {}
+        vel = max(float(ms["f64"].solution[n].data[I].abs().max()) for n in ms["f64"].names[:2])
         for n in ms["f64"].names:
             a, b = ms["f32"].solution[n].data[I].double(), ms["f64"].solution[n].data[I]
-            r[n] = float((a - b).abs().max() / b.abs().max())
+            # u and v are measured against the common velocity scale: v is a 1e-4 perturbation of a jet with |u| ~ 1
+            ref = vel if n in ms["f64"].names[:2] else float(b.abs().max())
+            r[n] = float((a - b).abs().max()) / ref
             assert r[n] <= bar, (n, nsteps, r[n])
         rec[f"state_after_{nsteps}_steps"] = r
     e64, e32 = ms["f64"].diagnostics()["total_energy"], ms["f32"].diagnostics()["total_energy"]
