@@ -49,8 +49,8 @@ extern "C" {
 #define SWMHD_TILE_KERNEL 2   /* force the LDS-tiled kernel.  Default (neither bit): chosen by size -- tiles for small grids and thin  */
 #define SWMHD_MARCH_KERNEL 4  /* force the row-marching kernel.   strips, row-marching from ~0.3-2 Mcell up (per entry point)          */
                               /* (8 is unassigned: it selected an experimental kernel that was removed)                               */
-#define SWMHD_WRAP_X 16       /* swmhd_tendencies_rk3 / swmhd_step_rk3: fuse the periodic halo fill of the NEW state into the kernel   */
-#define SWMHD_WRAP_Y 32       /*   (x images / y images; both = no halo-fill launch at all on a periodic single-GPU grid)              */
+#define SWMHD_WRAP_X 16       /* tendency entry points: READ the inputs with periodic index wrapping in x / in y -- cell (x mod Nx,    */
+#define SWMHD_WRAP_Y 32       /*   y mod Ny) instead of the halo cell -- so those halos need not be filled (no halo launch per stage)  */
 #define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels of
                                  another stream (the ring's halo exchange and boundary strips) can start while it runs                */
 
@@ -181,11 +181,11 @@ int swmhd_rk3_substep_f32(float *const *U, const float *const *Gn, const float *
  *     qnew[f] = q[f] + dt * (gamma * Gn[f] + zeta * Gm[f])                     (Gm == NULL: first-stage form)
  * q, qnew, Gn, Gm are HOST arrays of 4 device pointers (parents) in the order (u|uh, v|vh, h, A).  qnew must not
  * alias q: neighbouring workgroups still read the old state through their halos (ping-pong the two sets).
- * Only the interior of qnew is written (fill its halos before the next stage) unless flags carry SWMHD_WRAP_X / SWMHD_WRAP_Y:
- * then the periodic images of every new value are written into qnew's halo by the same kernel (needs Nx >= Hx, Ny >= Hy;
- * implemented by the LDS-tiled kernel, which these flags therefore select -- meant for grids below ~0.3 Mcell, where the
- * saved launches matter).
- * With row ranges (j_begin, j_end) the images are written for the rows computed.  The last stage of a step may pass
+ * Only the interior of qnew is written.  Periodic grids have two ways to give the next stage its halo values: fill qnew's halos
+ * (swmhd_fill_halo_periodic_multi), or pass SWMHD_WRAP_X / SWMHD_WRAP_Y to the NEXT call, which then reads (x mod Nx, y mod Ny)
+ * instead of the halo cells (needs Nx >= Hx, Ny >= Hy; every tendency kernel implements it, at no measurable cost).  The flags
+ * also apply to swmhd_tendencies.
+ * The last stage of a step may pass
  * store_G = 0 (the next step's first stage has zeta = 0 and never reads it).
  * ---------------------------------------------------------------------------------------------- */
 int swmhd_tendencies_rk3_f64(const double *const *q, double *const *qnew, double *const *Gn, const double *const *Gm,
@@ -203,7 +203,9 @@ int swmhd_tendencies_rk3_f32(const float *const *q, float *const *qnew, float *c
  * Native step driver: `nsteps` complete RK3 time steps of the periodic single-GPU model, i.e. Oceananigans'
  * time_step!(model, dt) (timestepper = :RungeKutta3, SWMHD_example.jl:23,42 / divergence_sw_mhd.jl:20,39) repeated:
  *     3 x { swmhd_tendencies_rk3 (gamma, zeta of the stage) ; swap state sets ; swap G sets ; periodic halo fill }
- * All 6*nsteps launches are enqueued on `stream` by this one call (capturable into a HIP graph).
+ * All 6*nsteps launches are enqueued on `stream` by this one call (capturable into a HIP graph).  With SWMHD_WRAP_X | SWMHD_WRAP_Y
+ * the halo fills are dropped (3 launches per step) and the halos of the returned state are STALE: fill them
+ * (swmhd_fill_halo_periodic_multi) before anything but a WRAP-flagged tendency call reads them.
  *   q      HOST array of 4 parents (u|uh, v|vh, h, A): the current state, halos filled
  *   q_alt  second set of 4 parents (scratch on entry)
  *   Ga,Gb  two sets of 4 tendency parents (scratch)
@@ -261,7 +263,8 @@ int swmhd_ring_exchange_y_f32(swmhd_ring *ring, float *const *fields, int nfield
  *   entry: halos of q current (x and y) -- or the exchange this ring left in flight for exactly this state
  *   exit : the y exchange of the final state is IN FLIGHT on the comm stream: call swmhd_ring_join(ring, stream) before
  *          anything but swmhd_ring_step_rk3 reads the y halos (or reuses the buffers) on `stream`
- * flags must not carry SWMHD_WRAP_X/Y; Ny >= 2*Hy+1.  Other arguments and state_in_alt as swmhd_step_rk3. */
+ * flags must not carry SWMHD_WRAP_Y (y images belong to the neighbours); with SWMHD_WRAP_X no x-halo kernel runs between a stage and
+ * its exchange and the x halos of the returned state are stale.  Ny >= 2*Hy+1.  Other arguments and state_in_alt as swmhd_step_rk3. */
 int swmhd_ring_step_rk3_f64(swmhd_ring *ring, double *const *q, double *const *q_alt, double *const *Ga, double *const *Gb,
                             int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
                             double g, double f, int formulation, int lorentz, double dt, int nsteps,

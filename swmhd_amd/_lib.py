@@ -108,11 +108,12 @@ def lib():
     """Load libswmhd.so (built in-tree by __graft_entry__.build() / swmhd_amd/csrc/Makefile)."""
     global _LIB
     if _LIB is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("SWMHD_LIBRARY", LIB_PATH)     # A/B builds of the same library (tools/): never a different backend
+        if not os.path.exists(path):
             raise SwmhdError(
-                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  swmhd_amd has no CPU fallback.")
-        _LIB = C.CDLL(LIB_PATH)
+        _LIB = C.CDLL(path)
         _declare(_LIB)
     return _LIB
 

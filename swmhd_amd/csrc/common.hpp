@@ -50,7 +50,8 @@ struct TendArgs {
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
-    int wrap;             // fused periodic halo fill of the NEW state: bit0 = x images, bit1 = y images (0: caller fills halos)
+    int wrap;             // periodic index wrapping of the READS: bit0 = x, bit1 = y -- the kernel takes (x mod Nx, y mod Ny) instead of the
+                          // halo cells, so the caller need not have filled those halos (no halo-fill launch between RK3 stages)
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
     int leave_room;       // marching kernels: leave ~5 % of the workgroup slots free for another stream's kernels
     T *Unew[4];
@@ -179,26 +180,13 @@ template <typename T>
 hipError_t launch_diagnostics(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny, int j0, int j1, long sy, T dx, T dy,
                               T grav, T href, int form, double *workspace, double *out, hipStream_t s);
 
-// Periodic halo fill fused into the state store ("scatter on write"), TILE kernel only: the lane that produces interior cell
-// (x, y) of the new state also writes its periodic images into the halo -- (x +- Nx, y), (x, y +- Ny) and the corner images --
-// so small grids (the reference's own 64^2 .. 128^2) need no halo-fill launch: 3 launches per RK3 step instead of 6.
-// Only cells within Hx / Hy of a domain edge store anything extra; general for N < 2H.  (Tried in the marching kernels too:
-// inlined it costs them their 3-waves/SIMD register allocation, out of line the call ABI costs more; they keep the 5-us halo
-// kernel, 1 % of a 4096^2 step.)
-template <typename T>
-__device__ __forceinline__ void store_wrapped(const TendArgs<T> &a, T *interior, int x, int y, T v) {
-    interior[(long)y * a.sy + x] = v;
-    if (!a.wrap) return;
-    const bool xw = (a.wrap & 1) && (x < a.Hx), xe = (a.wrap & 1) && (x >= a.Nx - a.Hx);
-    const bool ys = (a.wrap & 2) && (y < a.Hy), yn = (a.wrap & 2) && (y >= a.Ny - a.Hy);
-    if (!(xw || xe || ys || yn)) return;
-    for (int dy = -1; dy <= 1; ++dy) {
-        if ((dy == 1 && !ys) || (dy == -1 && !yn)) continue;
-        for (int dx = -1; dx <= 1; ++dx) {
-            if ((dx == 1 && !xw) || (dx == -1 && !xe) || (dx == 0 && dy == 0)) continue;
-            interior[(long)(y + dy * a.Ny) * a.sy + (x + dx * a.Nx)] = v;
-        }
-    }
+// Periodic "gather on read": with TendArgs::wrap the tendency kernels map a halo index to its periodic image in the interior when
+// they LOAD (one integer select per row / per lane, outside the arithmetic), so the state needs no halo-fill launch between RK3
+// stages: 3 launches per step instead of 6 on one GPU, and no x-halo kernel in front of the ring exchange on a slab.  (Round 1 had
+// the tile kernel scatter the images on write instead; that could not serve the marching kernels without costing them registers.)
+__device__ __forceinline__ int wrap_index(int v, int n, int lo, int hi, bool wrap) {
+    if (wrap) v = v < 0 ? v + n : (v >= n ? v - n : v);
+    return v < lo ? lo : (v > hi ? hi : v);   // (lanes / rows beyond one period only feed outputs that are never stored)
 }
 
 // XCD-aware block remap (cdna_hip_programming.md T1): hardware deals consecutive block ids round-robin

@@ -133,7 +133,7 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
               T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, int nsteps, int flags, int *state_in_alt,
               void *stream) {
     if (!r || !q || !q_alt || !Ga || !Gb || nsteps < 0) return SWMHD_EINVAL;
-    if (flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) return SWMHD_EINVAL;   // y images belong to the neighbours
+    if (flags & SWMHD_WRAP_Y) return SWMHD_EINVAL;   // y images belong to the neighbours (x may be wrapped on read: no x-halo kernel then)
     if (Ny < 2 * Hy + 1) return SWMHD_EINVAL;                          // a slab needs interior rows between its two strips
     const T gam[3] = {T(8.0 / 15.0), T(5.0 / 12.0), T(3.0 / 4.0)};
     const T zet[3] = {T(0), T(-17.0 / 60.0), T(-5.0 / 12.0)};
@@ -196,7 +196,7 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
             for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
             ++swaps;
             r->pending = nullptr;   // the exchange of the OLD state has been consumed; none of the new state is in flight yet
-            if ((rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return bail(rc);
+            if (!(flags & SWMHD_WRAP_X) && (rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return bail(rc);
             if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return bail(hipfail(r, "record", e));
             if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
             if ((rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c))) return bail(rc);

@@ -76,7 +76,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
     if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM)) return SWMHD_EINVAL;
-    if ((flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) && (!rk || Hx > Nx || Hy > Ny)) return rk ? SWMHD_EHALO : SWMHD_EINVAL;
+    if (((flags & SWMHD_WRAP_X) && Hx > Nx) || ((flags & SWMHD_WRAP_Y) && Hy > Ny)) return SWMHD_EHALO;   // one period must cover the halo
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
     const bool ok = lorentz == SWMHD_LORENTZ_NONE || (formulation == SWMHD_VECTOR_INVARIANT && lorentz == SWMHD_LORENTZ_JACOBIAN) ||

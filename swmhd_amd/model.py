@@ -39,13 +39,16 @@ class ShallowWaterModel:
         self.names = (n1, n2, "h", "A")
         locs = ((Face, Center), (Center, Face), (Center, Center), (Center, Center))
         mk = lambda loc: Field(grid, loc, dtype, device)
-        self.solution = {n: mk(l) for n, l in zip(self.names, locs)}
+        self._state = {n: mk(l) for n, l in zip(self.names, locs)}
         self.fused = fused                    # one kernel per RK3 stage (tendencies + substep), state ping-ponged
-        # periodic halo fill fused into the stage kernel ("scatter on write"): x and y images on one GPU, x images on a slab
-        self._wrap = 0
-        # Only where the tile kernel runs anyway (small grids): the marching kernels keep the separate 5-us halo launch.
-        if fused and fuse_halo and grid.Nx >= grid.Hx and grid.Ny >= grid.Hy and grid.Nx * grid.Ny <= 300000 and kernel in (None, "auto", "tile"):
-            self._wrap = _lib.WRAP_X | (_lib.WRAP_Y if (decomp is None or not decomp.ring) else 0)
+        # Periodic "gather on read" (SWMHD_WRAP_X / _Y): the tendency kernels take the periodic image instead of the halo cell, so
+        # no halo-fill launch runs between RK3 stages -- x and y on one GPU, x on a slab (its y halos come from the ring).  The halos
+        # of the state are then filled lazily, when something other than a tendency kernel is about to read them (_ensure_halos).
+        self._rwrap = 0
+        if fuse_halo and grid.Nx >= grid.Hx and grid.Ny >= grid.Hy:
+            self._rwrap = _lib.WRAP_X | (0 if self.decomp.ring else _lib.WRAP_Y)
+        self._halo_stale = False
+        self._exchange_in_flight = False      # torch p2p overlap path: a y exchange is queued on the comm stream
         self._alt = {n: mk(l) for n, l in zip(self.names, locs)} if fused else None
         self.Gn = [mk(l) for l in locs]     # Gⁿ
         self.Gm = [mk(l) for l in locs]     # G⁻
@@ -54,7 +57,7 @@ class ShallowWaterModel:
         self._comm_stream = torch.cuda.Stream() if (self.decomp.ring and torch.cuda.is_available()) else None
         self._L = _lib.lib()
         self.tendency_events = None   # bench.py: list collecting (start, end) HIP events around every tendency launch
-        if any(not f.data.is_cuda for f in self.solution.values()):
+        if any(not f.data.is_cuda for f in self._state.values()):
             raise _lib.SwmhdError("ShallowWaterModel runs on the GPU only (no CPU fallback)")
         # y-slab ring: the native RCCL ring (swmhd_ring_*) when the process group is RCCL; torch.distributed p2p otherwise
         # (gloo rehearsals).  The ring's step driver needs the fused stage kernel and a slab taller than its two strips.
@@ -67,7 +70,7 @@ class ShallowWaterModel:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
             return None
-        dev = self.fields[0].data.device
+        dev = self._raw_fields[0].data.device
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy torch has loaded
         rccl = rccl.encode() if os.path.exists(rccl) else None
         ident = torch.zeros(_lib.RING_ID_BYTES, dtype=torch.uint8)
@@ -115,6 +118,7 @@ class ShallowWaterModel:
             self._ring_check(self._L.swmhd_ring_join(self._ring, _stream_ptr()), "swmhd_ring_join")
         if self._comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self._comm_stream)
+        self._exchange_in_flight = False
 
     def close(self):
         """Release the ring (RCCL communicator, comm stream).  Collective over the ranks like its creation; call it before
@@ -133,33 +137,51 @@ class ShallowWaterModel:
     def set(self, **kw):
         self._join()
         for k, v in kw.items():
-            self.solution[k].set(v)
+            self._state[k].set(v)
         self.update_state()
         return self
 
     @property
+    def solution(self):
+        """The prognostic fields by name (u|uh, v|vh, h, A), halos current."""
+        self._ensure_halos()
+        return self._state
+
+    @property
     def fields(self):
-        return [self.solution[n] for n in self.names]
+        self._ensure_halos()
+        return [self._state[n] for n in self.names]
+
+    @property
+    def _raw_fields(self):
+        """The prognostic fields without touching their halos (which may be stale between stages)."""
+        return [self._state[n] for n in self.names]
+
+    def _ensure_halos(self):
+        if self._halo_stale:
+            self.update_state()
 
     # --- update_state!: fill halos (periodic x locally; y locally or by ring exchange) --------------------------
     def _fill_x(self, stream=None):
         g = self.grid
-        ptrs = _lib.ptr_array([f.ptr for f in self.fields])
+        q = self._raw_fields
+        ptrs = _lib.ptr_array([f.ptr for f in q])
         which = _lib.HALO_X | (0 if self.decomp.ring else _lib.HALO_Y)
         f = getattr(self._L, f"swmhd_fill_halo_periodic_multi_{self.sfx}")
-        _lib.check(f(ptrs, 4, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, which, _stream_ptr(stream)), "fill_halo_multi")
+        _lib.check(f(ptrs, 4, g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, which, _stream_ptr(stream)), "fill_halo_multi")
 
     def update_state(self):
         self._join()
+        self._halo_stale = False
         self._fill_x()
+        q = self._raw_fields
         if self._ring is not None:
             g = self.grid
             f = getattr(self._L, f"swmhd_ring_exchange_y_{self.sfx}")
-            rc = f(self._ring, _lib.ptr_array([q.ptr for q in self.fields]), 4, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y,
-                   _stream_ptr())
+            rc = f(self._ring, _lib.ptr_array([x.ptr for x in q]), 4, g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, _stream_ptr())
             self._ring_check(rc, "swmhd_ring_exchange_y")
         elif self.decomp.ring:
-            exchange_y_halos([f.data for f in self.fields], self.grid.Ny, self.grid.Hy, self.decomp, self.group)
+            exchange_y_halos([f.data for f in q], self.grid.Ny, self.grid.Hy, self.decomp, self.group)
 
     # --- calculate_tendencies! ------------------------------------------------------------------------------
     def calculate_tendencies(self, rows=None, stream=None):
@@ -174,21 +196,21 @@ class ShallowWaterModel:
 
     def _calculate_tendencies(self, rows=None, stream=None):
         g = self.grid
-        q = self.fields
+        q = self._raw_fields
         j0, j1 = (0, g.Ny) if rows is None else rows
         f = getattr(self._L, f"swmhd_tendencies_{self.sfx}")
         rc = f(q[0].ptr, q[1].ptr, q[2].ptr, q[3].ptr, self.Gn[0].ptr, self.Gn[1].ptr, self.Gn[2].ptr, self.Gn[3].ptr,
                g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code, self.lorentz_code,
-               j0, j1, self._flags, _stream_ptr(stream))
+               j0, j1, self._flags | self._rwrap, _stream_ptr(stream))
         _lib.check(rc, "swmhd_tendencies")
 
     def _substep(self, dt, stage):
         g = self.grid
-        U = _lib.ptr_array([f.ptr for f in self.fields])
+        U = _lib.ptr_array([f.ptr for f in self._raw_fields])
         Gn = _lib.ptr_array([f.ptr for f in self.Gn])
         Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
         f = getattr(self._L, f"swmhd_rk3_substep_{self.sfx}")
-        rc = f(U, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 0, g.Ny,
+        rc = f(U, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self._raw_fields[0].stride_y, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 0, g.Ny,
                _lib.STRICT if self.strict else _lib.FAST, _stream_ptr())
         _lib.check(rc, "swmhd_rk3_substep")
 
@@ -197,7 +219,7 @@ class ShallowWaterModel:
         alternate buffers (swmhd_tendencies_rk3_*)."""
         g = self.grid
         j0, j1 = (0, g.Ny) if rows is None else rows
-        q = _lib.ptr_array([f.ptr for f in self.fields])
+        q = _lib.ptr_array([f.ptr for f in self._raw_fields])
         qn = _lib.ptr_array([self._alt[n].ptr for n in self.names])
         Gn = _lib.ptr_array([f.ptr for f in self.Gn])
         Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
@@ -206,9 +228,9 @@ class ShallowWaterModel:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self.fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
+        rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self._raw_fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
                self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
-               self._flags | self._wrap | extra_flags, _stream_ptr())
+               self._flags | self._rwrap | extra_flags, _stream_ptr())
         if timed:
             e1.record()
             self.tendency_events.append((e0, e1, j1 - j0))
@@ -220,17 +242,21 @@ class ShallowWaterModel:
         import ctypes
         gr = self.grid
         swapped = ctypes.c_int(0)
-        q = _lib.ptr_array([f.ptr for f in self.fields])
+        if self._halo_stale and not (self._rwrap & _lib.WRAP_X):
+            self.update_state()
+        q = _lib.ptr_array([f.ptr for f in self._raw_fields])
         qa = _lib.ptr_array([self._alt[nm].ptr for nm in self.names])
         Ga = _lib.ptr_array([f.ptr for f in self.Gn])
         Gb = _lib.ptr_array([f.ptr for f in self.Gm])
         f = getattr(self._L, f"swmhd_ring_step_rk3_{self.sfx}")
-        rc = f(self._ring, q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self.fields[0].stride_y, gr.dx, gr.dy, self.g, self.f,
-               self.form_code, self.lorentz_code, dt, n, self._flags, ctypes.byref(swapped), _stream_ptr())
+        rc = f(self._ring, q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self._raw_fields[0].stride_y, gr.dx, gr.dy, self.g, self.f,
+               self.form_code, self.lorentz_code, dt, n, self._flags | (self._rwrap & _lib.WRAP_X), ctypes.byref(swapped), _stream_ptr())
         self._ring_check(rc, "swmhd_ring_step_rk3")
         if swapped.value:
-            self.solution, self._alt = self._alt, self.solution
+            self._state, self._alt = self._alt, self._state
             self.Gn, self.Gm = self.Gm, self.Gn
+        if n > 0 and (self._rwrap & _lib.WRAP_X):
+            self._halo_stale = True       # x halos were not filled; the y exchange of the final state is in flight (see _join)
         self.clock_time += n * dt
         self.iteration += n
 
@@ -243,7 +269,7 @@ class ShallowWaterModel:
         for stage in range(3):
             # one RK3 stage over a row range: either the fused kernel or tendencies followed (later) by the substep
             run = (lambda rows=None, fl=0: self._stage_fused(dt, stage, rows, fl)) if self.fused else (lambda rows=None, fl=0: self.calculate_tendencies(rows=rows))
-            if overlap and self.iteration + stage > 0:
+            if overlap and self._exchange_in_flight:
                 # x halos are current; the y exchange of the previous stage is in flight on the comm stream.  Interior rows run
                 # on the main stream; the two H-row boundary strips are queued on the COMM stream behind the exchange, so they
                 # start the moment the halo rows land and overlap the tail of the interior kernel.
@@ -255,19 +281,22 @@ class ShallowWaterModel:
             else:
                 run()
             if self.fused:
-                self.solution, self._alt = self._alt, self.solution      # the new state becomes current
+                self._state, self._alt = self._alt, self._state      # the new state becomes current
             else:
                 self._substep(dt, stage)
             self.Gn, self.Gm = self.Gm, self.Gn          # store_tendencies!: G⁻ <- Gⁿ (pointer swap, 0 bytes)
-            if not (self.fused and self._wrap):
-                self._fill_x()                           # (the fused kernel already wrote the periodic images otherwise)
+            if not (self._rwrap & _lib.WRAP_X):
+                self._fill_x()                           # (otherwise the next stage reads the periodic images itself)
+            else:
+                self._halo_stale = True
             if multi:
                 if overlap:
                     self._comm_stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._comm_stream):
-                        exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
+                        exchange_y_halos([f.data for f in self._raw_fields], g.Ny, H, self.decomp, self.group)
+                    self._exchange_in_flight = True
                 else:
-                    exchange_y_halos([f.data for f in self.fields], g.Ny, H, self.decomp, self.group)
+                    exchange_y_halos([f.data for f in self._raw_fields], g.Ny, H, self.decomp, self.group)
         self.clock_time += dt
         self.iteration += 1
 
@@ -278,7 +307,8 @@ class ShallowWaterModel:
         G-/Gn pointers return to their original roles after an even number of stages.  `time_steps` then replays it."""
         if self.decomp.ring or not self.fused:
             raise _lib.SwmhdError("capture_graph: single-GPU fused path only (halo exchange is not capturable)")
-        keep = [f.data.clone() for f in self.fields] + [f.data.clone() for f in self.Gm]
+        self._ensure_halos()
+        keep = [f.data.clone() for f in self._raw_fields] + [f.data.clone() for f in self.Gm]
         t0, i0 = self.clock_time, self.iteration
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -292,14 +322,15 @@ class ShallowWaterModel:
         # the graph has the device pointers of THIS role assignment baked in (state in `solution`, scratch in `_alt`, Gn/Gm as
         # they are now): it may only be replayed while the roles are the same, i.e. after an even number of eager steps
         self._graph_roles = self._roles()
-        for f, k in zip(self.fields + self.Gm, keep):   # capture does not execute; undo the two warm-up steps
+        for f, k in zip(self._raw_fields + self.Gm, keep):   # capture does not execute; undo the two warm-up steps
             f.data.copy_(k)
+        self._halo_stale = False
         self.clock_time, self.iteration = t0, i0
         return self
 
     def _roles(self):
         """Which buffer plays which role right now (every RK3 step swaps state<->scratch and Gn<->G- an odd number of times)."""
-        return tuple(f.ptr for f in self.fields) + tuple(f.ptr for f in self.Gn)
+        return tuple(f.ptr for f in self._raw_fields) + tuple(f.ptr for f in self.Gn)
 
     def time_steps(self, n, dt):
         """n RK3 steps: graph replays (2 steps each) when a graph was captured for this dt; otherwise the native step driver
@@ -313,6 +344,7 @@ class ShallowWaterModel:
         if g is not None and self._graph_dt == dt and self._roles() == self._graph_roles:
             for _ in range(n // 2):
                 g.replay()
+                self._halo_stale = self._halo_stale or bool(self._rwrap)
                 self.clock_time += 2 * dt
                 self.iteration += 2
             n = n % 2
@@ -326,17 +358,19 @@ class ShallowWaterModel:
             gr = self.grid
             import ctypes
             swapped = ctypes.c_int(0)
-            q = _lib.ptr_array([f.ptr for f in self.fields])
+            q = _lib.ptr_array([f.ptr for f in self._raw_fields])
             qa = _lib.ptr_array([self._alt[nm].ptr for nm in self.names])
             Ga = _lib.ptr_array([f.ptr for f in self.Gn])
             Gb = _lib.ptr_array([f.ptr for f in self.Gm])
             f = getattr(self._L, f"swmhd_step_rk3_{self.sfx}")
-            rc = f(q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self.fields[0].stride_y, gr.dx, gr.dy, self.g, self.f, self.form_code,
-                   self.lorentz_code, dt, n, self._flags | self._wrap, ctypes.byref(swapped), _stream_ptr())
+            rc = f(q, qa, Ga, Gb, gr.Nx, gr.Ny, gr.Hx, gr.Hy, self._raw_fields[0].stride_y, gr.dx, gr.dy, self.g, self.f, self.form_code,
+                   self.lorentz_code, dt, n, self._flags | self._rwrap, ctypes.byref(swapped), _stream_ptr())
             _lib.check(rc, "swmhd_step_rk3")
             if swapped.value:
-                self.solution, self._alt = self._alt, self.solution
+                self._state, self._alt = self._alt, self._state
                 self.Gn, self.Gm = self.Gm, self.Gn
+            if n > 0 and self._rwrap:
+                self._halo_stale = True
             self.clock_time += n * dt
             self.iteration += n
             return
@@ -383,7 +417,8 @@ class ShallowWaterModel:
         import numpy as np
         self._join()
         z = np.load(path, allow_pickle=False)
-        for n, f in zip(self.names, self.fields):
+        self._halo_stale = False              # the checkpoint holds the parents, halos included
+        for n, f in zip(self.names, self._raw_fields):
             f.data.copy_(torch.from_numpy(z[n]).to(f.data.dtype))
         for n, f in zip(self.names, self.Gm):
             f.data.copy_(torch.from_numpy(z["Gm_" + n]).to(f.data.dtype))
@@ -391,5 +426,7 @@ class ShallowWaterModel:
         return self
 
     def synchronize(self):
+        """Wait for everything enqueued; afterwards the halos of the state are current (they are filled lazily, see __init__)."""
+        self._ensure_halos()
         self._join()
         torch.cuda.synchronize()
