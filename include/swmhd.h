@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SWMHD_VERSION 100
+#define SWMHD_VERSION 200
 
 /* flags (bit mask) */
 #define SWMHD_FAST 0
@@ -51,6 +51,8 @@ extern "C" {
                               /* (8 is unassigned: it selected an experimental kernel that was removed)                               */
 #define SWMHD_WRAP_X 16       /* tendency entry points: READ the inputs with periodic index wrapping in x / in y -- cell (x mod Nx,    */
 #define SWMHD_WRAP_Y 32       /*   y mod Ny) instead of the halo cell -- so those halos need not be filled (no halo launch per stage)  */
+#define SWMHD_BOUNDED_X 256    /* tendency entry points: the grid's topology in x / in y is Bounded (default: Periodic).  Reconstructions  */
+#define SWMHD_BOUNDED_Y 512    /*   near the walls use Oceananigans' boundary schemes, the divergence forcing the reference's wall branches */
 #define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels of
                                  another stream (the ring's halo exchange and boundary strips) can start while it runs                */
 
@@ -133,6 +135,23 @@ int swmhd_fill_halo_periodic_multi_f32(float *const *fields, int nfields, int Nx
                                        int64_t stride_y, int which, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * fill_halo_regions! for any pair of (Periodic | Bounded) topologies: what the models need between RK3 stages when a direction is
+ * Bounded -- the reference's scripts are written for it (Grids.topology tests throughout sw_mhd_divergence_functions.jl:42-125;
+ * the commented boundary conditions SWMHD_example.jl:18-19 / divergence_sw_mhd.jl:17 put GradientBoundaryCondition(-0.05) on the
+ * north and south sides of A).  Periodic directions: as swmhd_fill_halo_periodic.  Bounded directions (Oceananigans' defaults):
+ *   field at Center in that direction : no-flux -- halo point m mirrors interior point m;  with a gradient value g (not NaN) instead:
+ *                                       ONLY the first halo point, c[0] = c[1] - g*d, c[N+1] = c[N] + g*d (as the library fills it)
+ *   field at Face in that direction   : impenetrable wall -- c[1] = 0 and c[N+1] = 0 (the first halo line holds the far wall)
+ * West/east first, then south/north over the padded width.  fields: HOST array of nf (1..4) parents; face_x / face_y: bit f set =
+ * field f is located at Face in x / y; gradient: HOST array of 4*nf values (west, east, south, north per field; NaN = default),
+ * or NULL.  Two launches.
+ * ---------------------------------------------------------------------------------------------- */
+int swmhd_fill_halo_f64(double *const *fields, int nf, int Nx, int Ny, int Hx, int Hy, int64_t stride_y, int topo_x, int topo_y,
+                        int face_x, int face_y, const double *gradient, double dx, double dy, void *stream);
+int swmhd_fill_halo_f32(float *const *fields, int nf, int Nx, int Ny, int Hx, int Hy, int64_t stride_y, int topo_x, int topo_y,
+                        int face_x, int face_y, const float *gradient, float dx, float dy, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused tendency evaluation: the whole-field form of Oceananigans' ShallowWaterModel tendency kernels
  * (calculate_tendencies!) WITH the reference's forcing callback fused in -- one pass over the four
  * prognostic fields produces all four tendencies; the Lorentz force never round-trips through HBM.
@@ -143,7 +162,12 @@ int swmhd_fill_halo_periodic_multi_f32(float *const *fields, int nfields, int Nx
  *       model configuration of divergence_formulation/divergence_sw_mhd.jl:19-31
  * The base right-hand side is Oceananigans' (third-party, un-vendored by the reference): it is restated from
  * the library's published scheme, parity UNPINNED; the forcing is the reference's own.
- * All fields need halo >= 3, filled.  Rows j_begin+1..j_end are computed.
+ * All fields need halo >= 3, filled (swmhd_fill_halo for Bounded directions).  Rows j_begin+1..j_end are computed.
+ * flags SWMHD_BOUNDED_X / SWMHD_BOUNDED_Y: that direction is Bounded -- within the boundary buffers WENO5 drops to third- and
+ * first-order upwind and the centred fourth-order advecting velocity to second order (Oceananigans' topologically conditional
+ * interpolation, restated; parity UNPINNED), the divergence forcing takes the reference's wall branches, and the tendency of the
+ * wall-normal velocity ON the wall (index 1) is whatever the stencil gives: the caller's halo fill resets that line to zero, as
+ * Oceananigans' does.  Bounded grids run on the LDS-tiled kernel.  A direction cannot be both Bounded and SWMHD_WRAP-ped.
  * ---------------------------------------------------------------------------------------------- */
 #define SWMHD_CONSERVATIVE 0
 #define SWMHD_VECTOR_INVARIANT 1
@@ -203,6 +227,7 @@ int swmhd_tendencies_rk3_f32(const float *const *q, float *const *qnew, float *c
  * Native step driver: `nsteps` complete RK3 time steps of the periodic single-GPU model, i.e. Oceananigans'
  * time_step!(model, dt) (timestepper = :RungeKutta3, SWMHD_example.jl:23,42 / divergence_sw_mhd.jl:20,39) repeated:
  *     3 x { swmhd_tendencies_rk3 (gamma, zeta of the stage) ; swap state sets ; swap G sets ; periodic halo fill }
+ * Periodic grids only (SWMHD_BOUNDED_* -> SWMHD_ENOTSUP: drive the stages with swmhd_tendencies_rk3 + swmhd_fill_halo).
  * All 6*nsteps launches are enqueued on `stream` by this one call (capturable into a HIP graph).  With SWMHD_WRAP_X | SWMHD_WRAP_Y
  * the halo fills are dropped (3 launches per step) and the halos of the returned state are STALE: fill them
  * (swmhd_fill_halo_periodic_multi) before anything but a WRAP-flagged tendency call reads them.

@@ -47,13 +47,16 @@ def lib():
             f.argtypes = [p, p, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct, C.c_int, C.c_int, C.c_int]
             f.restype = C.c_int
             f = getattr(_LIB, f"oracle_tendencies_{sfx}")
-            f.argtypes = [p] * 8 + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, C.c_int]
+            f.argtypes = [p] * 8 + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
             f.restype = C.c_int
+            f = getattr(_LIB, f"oracle_fill_halo_{sfx}")
+            f.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, p, ct, ct]
+            f.restype = None
             f = getattr(_LIB, f"oracle_fill_halo_periodic_{sfx}")
             f.argtypes = [p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long]
             f.restype = None
             f = getattr(_LIB, f"oracle_time_step_{sfx}")
-            f.argtypes = [p] * 6 + [C.c_long] + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, ct, C.c_int]
+            f.argtypes = [p] * 6 + [C.c_long] + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, ct, C.c_int, C.c_int, p, C.c_int]
             f.restype = C.c_int
             f = getattr(_LIB, f"oracle_probe_{sfx}")
             f.argtypes = [C.c_int, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct,
@@ -118,14 +121,14 @@ CONSERVATIVE, VECTOR_INVARIANT = 0, 1
 LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = 0, 1, 2
 
 
-def tendencies(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, formulation, lorentz, g=9.81, f=1.0, nthreads=1):
-    """(G_q1, G_q2, G_h, G_A) for q = (uh, vh) [formulation 0] or (u, v) [formulation 1]; halos must be filled."""
+def tendencies(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, formulation, lorentz, g=9.81, f=1.0, nthreads=1, topo=(PERIODIC, PERIODIC)):
+    """(G_q1, G_q2, G_h, G_A) for q = (uh, vh) [formulation 0] or (u, v) [formulation 1]; halos must be filled (fill_halo)."""
     _check(q1, q2, h, A)
     assert A.shape == (Ny + 2 * Hy, Nx + 2 * Hx)
     G = [np.zeros_like(A) for _ in range(4)]
     rc = getattr(lib(), f"oracle_tendencies_{_sfx(A)}")(
         _ptr(q1), _ptr(q2), _ptr(h), _ptr(A), *[_ptr(x) for x in G], Nx, Ny, Hx, Hy, A.shape[1], dx, dy, g, f,
-        formulation, lorentz, nthreads)
+        formulation, lorentz, topo[0], topo[1], nthreads)
     if rc:
         raise ValueError(f"oracle_tendencies rc={rc}")
     return tuple(G)
@@ -137,7 +140,27 @@ def fill_halo_periodic(a, Nx, Ny, Hx, Hy):
     return a
 
 
-def time_step(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, dt, formulation, lorentz, g=9.81, f=1.0, nthreads=1, work=None):
+def _grad(a, grad):
+    """4 GradientBoundaryCondition values (west, east, south, north; None = default BC) as an array of a's dtype, NaN = default."""
+    g = np.full(4, np.nan, dtype=a.dtype)
+    for k, v in enumerate(grad or ()):
+        if v is not None:
+            g[k] = v
+    return g
+
+
+def fill_halo(a, Nx, Ny, Hx, Hy, topo=(PERIODIC, PERIODIC), face=(False, False), grad=None, dx=1.0, dy=1.0):
+    """fill_halo_regions! of one field in place: periodic wrap, or in Bounded directions the default BCs (no-flux mirror for
+    centre-located fields, impenetrable walls for the normal velocity) / GradientBoundaryCondition values grad = (w, e, s, n)."""
+    _check(a)
+    gr = _grad(a, grad)
+    getattr(lib(), f"oracle_fill_halo_{_sfx(a)}")(_ptr(a), Nx, Ny, Hx, Hy, a.shape[1], topo[0], topo[1], int(face[0]), int(face[1]),
+                                                   _ptr(gr), dx, dy)
+    return a
+
+
+def time_step(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, dt, formulation, lorentz, g=9.81, f=1.0, nthreads=1, work=None,
+              topo=(PERIODIC, PERIODIC), gradA=None):
     """One RK3 step in place (RungeKutta3: γ = 8/15, 5/12, 3/4; ζ = -17/60, -5/12).  Halos filled on entry and exit."""
     _check(q1, q2, h, A)
     n = A.size
@@ -145,7 +168,7 @@ def time_step(q1, q2, h, A, Nx, Ny, Hx, Hy, dx, dy, dt, formulation, lorentz, g=
         work = (np.zeros(4 * n, A.dtype), np.zeros(4 * n, A.dtype))
     rc = getattr(lib(), f"oracle_time_step_{_sfx(A)}")(
         _ptr(q1), _ptr(q2), _ptr(h), _ptr(A), _ptr(work[0]), _ptr(work[1]), n, Nx, Ny, Hx, Hy, A.shape[1], dx, dy, g, f,
-        formulation, lorentz, dt, nthreads)
+        formulation, lorentz, dt, topo[0], topo[1], _ptr(_grad(A, gradA)), nthreads)
     if rc:
         raise ValueError(f"oracle_time_step rc={rc}")
     return work

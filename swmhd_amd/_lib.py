@@ -13,6 +13,7 @@ TILE_KERNEL = 2
 MARCH_KERNEL = 4
 WRAP_X, WRAP_Y = 16, 32
 LEAVE_ROOM = 64
+BOUNDED_X, BOUNDED_Y = 256, 512
 KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4}
 PERIODIC, BOUNDED = 0, 1
 HALO_X, HALO_Y = 1, 2
@@ -48,6 +49,9 @@ def _declare(lib):
         f.restype = i
         f = getattr(lib, f"swmhd_fill_halo_periodic_{sfx}")
         f.argtypes = [p, i, i, i, i, i64, i, p]
+        f.restype = i
+        f = getattr(lib, f"swmhd_fill_halo_{sfx}")
+        f.argtypes = [C.POINTER(p), i, i, i, i, i, i64, i, i, i, i, p, ft, ft, p]
         f.restype = i
         f = getattr(lib, f"swmhd_fill_halo_periodic_multi_{sfx}")
         f.argtypes = [C.POINTER(p), i, i, i, i, i, i64, i, p]
@@ -97,7 +101,7 @@ def _declare(lib):
 EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
-        "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
+        "fill_halo", "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
         "ring_exchange_y", "ring_step_rk3")] + [
     "swmhd_ring_" + name for name in ("unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
                                       "launch_times")]

@@ -37,6 +37,18 @@ hipError_t launch_fill_halo_periodic(T *interior, int Nx, int Ny, int Hx, int Hy
 template <typename T>
 hipError_t launch_fill_halo_periodic_multi(T *const *interiors, int nfields, int Nx, int Ny, int Hx, int Hy, long sy,
                                            int which, hipStream_t s);
+// fill_halo_regions! for any (Periodic | Bounded) topology pair with Oceananigans' default boundary conditions or gradient BCs
+// (oracle_fill_halo): west/east pass, then south/north pass over the padded width.  face_x/face_y: bit f set = field f is
+// located at Face in that direction; grad[f][4] = west, east, south, north GradientBoundaryCondition values (NaN = default).
+template <typename T>
+struct HaloBc {
+    T *f[4];
+    T grad[4][4];
+    int nf, Nx, Ny, Hx, Hy, topo_x, topo_y, face_x, face_y;
+    long sy;
+    T dx, dy;
+};
+template <typename T> hipError_t launch_fill_halo_bc(const HaloBc<T> &a, hipStream_t s);
 
 // Arguments of the fused tendency kernels; pointers address interior cell (1,1) like OpArgs.
 template <typename T>
@@ -53,6 +65,7 @@ struct TendArgs {
     int wrap;             // periodic index wrapping of the READS: bit0 = x, bit1 = y -- the kernel takes (x mod Nx, y mod Ny) instead of the
                           // halo cells, so the caller need not have filled those halos (no halo-fill launch between RK3 stages)
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
+    int topo_x, topo_y;   // 0 Periodic, 1 Bounded (wall orders of the reconstructions; the LDS-tiled kernel implements them)
     int leave_room;       // marching kernels: leave ~5 % of the workgroup slots free for another stream's kernels
     T *Unew[4];
     const T *Gm[4];

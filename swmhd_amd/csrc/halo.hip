@@ -1,6 +1,8 @@
 // Periodic halo fill: the stand-alone engine's counterpart of Oceananigans' fill_halo_regions! for
 // topology = (Periodic, Periodic, Flat) (reference: jacobian_formulation/SWMHD_example.jl:16).
 #include "common.hpp"
+// (gradient boundary values are formed as c - g*d in two roundings, like the oracle: no FMA contraction in this file)
+#pragma clang fp contract(off)
 
 namespace swmhd {
 namespace {
@@ -64,7 +66,44 @@ __global__ void k_halo_multi(HaloMulti<T> a) {
     for (int k = 0; k < a.nf; ++k) a.f[k][dst] = a.f[k][src];
 }
 
+// fill_halo_regions! with boundary conditions, one pass per direction (x pass over interior rows, then y pass over the padded
+// width, like the oracle and like Oceananigans' west/east-then-south/north order).  One thread per (field, line): the line's halo
+// cells are few (<= 2 Hx) and the passes are launch-latency bound anyway.
+template <typename T, int DIR>
+__global__ void k_halo_bc(HaloBc<T> a) {
+    const int nlines = DIR == 0 ? a.Ny : a.Nx + 2 * a.Hx;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines * a.nf) return;
+    const int fld = t / nlines, line = t - fld * nlines;
+    T *f = a.f[fld];
+    const int N = DIR == 0 ? a.Nx : a.Ny, H = DIR == 0 ? a.Hx : a.Hy;
+    const int topo = DIR == 0 ? a.topo_x : a.topo_y;
+    const bool face = ((DIR == 0 ? a.face_x : a.face_y) >> fld) & 1;
+    const T d = DIR == 0 ? a.dx : a.dy;
+    const T glo = a.grad[fld][DIR == 0 ? 0 : 2], ghi = a.grad[fld][DIR == 0 ? 1 : 3];
+    // element k (0-based along the direction, halo cells have k < 0 or k >= N) of this line
+    auto at = [&](int k) -> T & { return DIR == 0 ? f[(long)line * a.sy + k] : f[(long)k * a.sy + (line - a.Hx)]; };
+    if (topo == 0) {
+        for (int m = 1; m <= H; ++m) { at(-m) = at(N - m); at(N + m - 1) = at(m - 1); }
+    } else if (face) {
+        at(0) = T(0); at(N) = T(0);                         // impenetrable walls: Julia indices 1 and N+1
+    } else {
+        if (glo == glo) at(-1) = at(0) - glo * d; else for (int m = 1; m <= H; ++m) at(-m) = at(m - 1);
+        if (ghi == ghi) at(N) = at(N - 1) + ghi * d; else for (int m = 1; m <= H; ++m) at(N + m - 1) = at(N - m);
+    }
+}
+
 }  // namespace
+
+template <typename T>
+hipError_t launch_fill_halo_bc(const HaloBc<T> &a, hipStream_t s) {
+    const int nx = a.Ny * a.nf, ny = (a.Nx + 2 * a.Hx) * a.nf;
+    hipLaunchKernelGGL((k_halo_bc<T, 0>), dim3((nx + 127) / 128), dim3(128), 0, s, a);
+    hipLaunchKernelGGL((k_halo_bc<T, 1>), dim3((ny + 127) / 128), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+template hipError_t launch_fill_halo_bc<double>(const HaloBc<double> &, hipStream_t);
+template hipError_t launch_fill_halo_bc<float>(const HaloBc<float> &, hipStream_t);
 
 template <typename T>
 hipError_t launch_fill_halo_periodic_multi(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, long sy, int which,

@@ -2,6 +2,7 @@
 // global state; every call only enqueues work on the caller's stream.
 #include "../../include/swmhd.h"
 #include "common.hpp"
+#include <math.h>
 
 using namespace swmhd;
 
@@ -60,6 +61,28 @@ int halo_multi_common(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64
 }
 
 template <typename T>
+int halo_bc_common(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy, int topo_x, int topo_y, int face_x, int face_y,
+                   const T *gradient, T dx, T dy, void *stream) {
+    if (!f || nf < 1 || nf > 4 || Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
+    if ((topo_x != SWMHD_BOUNDED && topo_x != SWMHD_PERIODIC) || (topo_y != SWMHD_BOUNDED && topo_y != SWMHD_PERIODIC)) return SWMHD_EINVAL;
+    if (Hx > Nx || Hy > Ny) return SWMHD_EHALO;
+    if ((topo_x == SWMHD_BOUNDED && Hx < 1) || (topo_y == SWMHD_BOUNDED && Hy < 1)) return SWMHD_EHALO;   // the far wall lives in the first halo line
+    if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
+    HaloBc<T> a;
+    for (int k = 0; k < 4; ++k) {
+        a.f[k] = nullptr;
+        for (int e = 0; e < 4; ++e) a.grad[k][e] = (gradient && k < nf) ? gradient[4 * k + e] : T(NAN);
+    }
+    for (int k = 0; k < nf; ++k) {
+        if (!f[k]) return SWMHD_EINVAL;
+        a.f[k] = f[k] + (long)Hy * sy + Hx;
+    }
+    a.nf = nf; a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.topo_x = topo_x; a.topo_y = topo_y; a.face_x = face_x; a.face_y = face_y;
+    a.sy = (long)sy; a.dx = dx; a.dy = dy;
+    return hiprc(launch_fill_halo_bc<T>(a, (hipStream_t)stream));
+}
+
+template <typename T>
 struct FuseRk3 {
     T *Unew[4];
     const T *const *Gm;
@@ -75,7 +98,9 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
-    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM)) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_EINVAL;
+    if (((flags & SWMHD_BOUNDED_X) && (flags & SWMHD_WRAP_X)) || ((flags & SWMHD_BOUNDED_Y) && (flags & SWMHD_WRAP_Y))) return SWMHD_EINVAL;
+    if ((flags & (SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) && (flags & SWMHD_MARCH_KERNEL)) return SWMHD_ENOTSUP;   // walls: LDS-tiled kernel only
     if (((flags & SWMHD_WRAP_X) && Hx > Nx) || ((flags & SWMHD_WRAP_Y) && Hy > Ny)) return SWMHD_EHALO;   // one period must cover the halo
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     // the Jacobian forcing acts on (u, v), the divergence forcing on (uh, vh)  (SWMHD_example.jl:30-31, divergence_sw_mhd.jl:28-29)
@@ -93,6 +118,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
+    a.topo_x = (flags & SWMHD_BOUNDED_X) ? SWMHD_BOUNDED : SWMHD_PERIODIC; a.topo_y = (flags & SWMHD_BOUNDED_Y) ? SWMHD_BOUNDED : SWMHD_PERIODIC;
     a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : 0);
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
     if (rk) {
@@ -139,6 +165,7 @@ template <typename T>
 int step_common(T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny, int Hx, int Hy, int64_t sy, T dx, T dy, T grav,
                 T fcor, int formulation, int lorentz, T dt, int nsteps, int flags, int *state_in_alt, void *stream) {
     if (!q || !q_alt || !Ga || !Gb || nsteps < 0) return SWMHD_EINVAL;
+    if (flags & (SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_ENOTSUP;   // the driver's halo fill is the periodic one
     // RungeKutta3 coefficients (Oceananigans TimeSteppers: gamma = 8/15, 5/12, 3/4; zeta = -, -17/60, -5/12)
     const T gam[3] = {T(8.0 / 15.0), T(5.0 / 12.0), T(3.0 / 4.0)};
     const T zet[3] = {T(0), T(-17.0 / 60.0), T(-5.0 / 12.0)};
@@ -225,6 +252,10 @@ int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_s
     }                                                                                                                  \
     int swmhd_fill_halo_periodic_##sfx(T *f, int Nx, int Ny, int Hx, int Hy, int64_t sy, int which, void *stream) {    \
         return halo_common<T>(f, Nx, Ny, Hx, Hy, sy, which, stream);                                                   \
+    }                                                                                                                  \
+    int swmhd_fill_halo_##sfx(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy, int topo_x, int topo_y,  \
+                              int face_x, int face_y, const T *gradient, T dx, T dy, void *stream) {                       \
+        return halo_bc_common<T>(f, nf, Nx, Ny, Hx, Hy, sy, topo_x, topo_y, face_x, face_y, gradient, dx, dy, stream);     \
     }                                                                                                                  \
     int swmhd_fill_halo_periodic_multi_##sfx(T *const *f, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy,          \
                                              int which, void *stream) {                                                \

@@ -46,13 +46,19 @@ class Field:
         self.data.copy_(torch.from_numpy(arr).to(self.data.dtype))
         return self
 
-    def fill_halo_regions(self, stream=None):
-        """Periodic halo fill on the device (swmhd_fill_halo_periodic_*)."""
+    def fill_halo_regions(self, stream=None, boundary_conditions=None):
+        """fill_halo_regions!(field) on the device: periodic copy in Periodic directions; in Bounded ones the default boundary condition
+        of this field's location (no-flux mirror / impenetrable wall) or the given FieldBoundaryConditions (swmhd_fill_halo_*)."""
+        import ctypes
         g = self.grid
-        which = (_lib.HALO_X if g.topology[0] == "Periodic" else 0) | (_lib.HALO_Y if g.topology[1] == "Periodic" else 0)
-        f = getattr(_lib.lib(), f"swmhd_fill_halo_periodic_{_SFX[self.data.dtype]}")
-        _lib.check(f(self.data.data_ptr(), g.Nx, g.Ny, g.Hx, g.Hy, self.stride_y, which, _stream_ptr(stream)),
-                   "swmhd_fill_halo_periodic")
+        sfx = _SFX[self.data.dtype]
+        tx, ty = g.topo_codes()
+        ct = ctypes.c_double if sfx == "f64" else ctypes.c_float
+        grads = boundary_conditions.gradients() if boundary_conditions is not None else [float("nan")] * 4
+        f = getattr(_lib.lib(), f"swmhd_fill_halo_{sfx}")
+        rc = f(_lib.ptr_array([self.data.data_ptr()]), 1, g.Nx, g.Ny, g.Hx, g.Hy, self.stride_y, tx, ty,
+               1 if self.loc[0] == Face else 0, 1 if self.loc[1] == Face else 0, (ct * 4)(*grads), g.dx, g.dy, _stream_ptr(stream))
+        _lib.check(rc, "swmhd_fill_halo")
         return self
 
     @property

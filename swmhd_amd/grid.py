@@ -60,3 +60,24 @@ class RectilinearGrid:
     def topo_codes(self):
         code = {Periodic: 0, Bounded: 1}
         return code[self.topology[0]], code[self.topology[1]]
+
+
+# --- boundary conditions (the names the reference's commented lines use: SWMHD_example.jl:18-19, divergence_sw_mhd.jl:17) ---------
+@dataclass
+class GradientBoundaryCondition:
+    """GradientBoundaryCondition(g): the first halo point is linearly extrapolated with slope g (Oceananigans fills only that one)."""
+    gradient: float
+
+
+@dataclass
+class FieldBoundaryConditions:
+    """FieldBoundaryConditions(north = GradientBoundaryCondition(-0.05), south = ...): sides left at None keep the default of the
+    field's location (no-flux for centre-located fields, impenetrable walls for the normal velocity).  Bounded directions only."""
+    west: GradientBoundaryCondition = None
+    east: GradientBoundaryCondition = None
+    south: GradientBoundaryCondition = None
+    north: GradientBoundaryCondition = None
+
+    def gradients(self):
+        """(west, east, south, north) as floats, NaN = default boundary condition."""
+        return [float("nan") if b is None else float(b.gradient) for b in (self.west, self.east, self.south, self.north)]

@@ -23,7 +23,7 @@ RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True, fused=True, kernel="auto", fuse_halo=True, native_ring=True):
+                 overlap=True, fused=True, kernel="auto", fuse_halo=True, native_ring=True, boundary_conditions=None):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -33,7 +33,20 @@ class ShallowWaterModel:
             self.lorentz_code = _lib.LORENTZ_JACOBIAN if self.form_code == _lib.VECTOR_INVARIANT else _lib.LORENTZ_DIVERGENCE
         self.strict = strict
         self._flags = (_lib.STRICT if strict else _lib.FAST) | _lib.KERNEL_FLAGS[kernel]
+        # topology = (Periodic | Bounded, Periodic | Bounded, Flat): Bounded directions get wall reconstructions in the kernels
+        # (SWMHD_BOUNDED_X / _Y) and the boundary-condition halo fill (swmhd_fill_halo) instead of the periodic copy
+        tx, ty = grid.topo_codes()
+        self._bounded = (tx == _lib.BOUNDED, ty == _lib.BOUNDED)
+        self._flags |= (_lib.BOUNDED_X if self._bounded[0] else 0) | (_lib.BOUNDED_Y if self._bounded[1] else 0)
         self.decomp = decomp or SlabDecomposition(grid.Ny_global, 1, 0)
+        if any(self._bounded) and self.decomp.ring:
+            raise _lib.SwmhdError("y-slab decomposition (ring halo exchange) supports (Periodic, Periodic) grids only (SWMHD_ENOTSUP)")
+        # boundary_conditions = {"A": FieldBoundaryConditions(north = GradientBoundaryCondition(-0.05), ...)}  (SWMHD_example.jl:18-22)
+        self.boundary_conditions = dict(boundary_conditions or {})
+        for name, bc in self.boundary_conditions.items():
+            sides = [(bc.west, 0), (bc.east, 0), (bc.south, 1), (bc.north, 1)]
+            if any(b is not None and not self._bounded[d] for b, d in sides):
+                raise _lib.SwmhdError(f"boundary condition on a Periodic side of {name} (Oceananigans rejects it as well)")
         self.group, self.overlap = group, overlap
         n1, n2 = ("u", "v") if self.form_code == _lib.VECTOR_INVARIANT else ("uh", "vh")
         self.names = (n1, n2, "h", "A")
@@ -46,7 +59,7 @@ class ShallowWaterModel:
         # of the state are then filled lazily, when something other than a tendency kernel is about to read them (_ensure_halos).
         self._rwrap = 0
         if fuse_halo and grid.Nx >= grid.Hx and grid.Ny >= grid.Hy:
-            self._rwrap = _lib.WRAP_X | (0 if self.decomp.ring else _lib.WRAP_Y)
+            self._rwrap = (0 if self._bounded[0] else _lib.WRAP_X) | (0 if (self.decomp.ring or self._bounded[1]) else _lib.WRAP_Y)
         self._halo_stale = False
         self._exchange_in_flight = False      # torch p2p overlap path: a y exchange is queued on the comm stream
         self._alt = {n: mk(l) for n, l in zip(self.names, locs)} if fused else None
@@ -162,7 +175,25 @@ class ShallowWaterModel:
             self.update_state()
 
     # --- update_state!: fill halos (periodic x locally; y locally or by ring exchange) --------------------------
+    def _fill_bc(self, stream=None):
+        """fill_halo_regions! with boundary conditions (at least one Bounded direction): swmhd_fill_halo."""
+        import ctypes
+        g = self.grid
+        q = self._raw_fields
+        ct = ctypes.c_double if self.sfx == "f64" else ctypes.c_float
+        grads = []
+        for n in self.names:
+            bc = self.boundary_conditions.get(n)
+            grads += bc.gradients() if bc is not None else [float("nan")] * 4
+        f = getattr(self._L, f"swmhd_fill_halo_{self.sfx}")
+        tx, ty = g.topo_codes()
+        rc = f(_lib.ptr_array([x.ptr for x in q]), 4, g.Nx, g.Ny, g.Hx, g.Hy, q[0].stride_y, tx, ty, 0b0001, 0b0010,
+               (ct * 16)(*grads), g.dx, g.dy, _stream_ptr(stream))
+        _lib.check(rc, "swmhd_fill_halo")
+
     def _fill_x(self, stream=None):
+        if any(self._bounded):
+            return self._fill_bc(stream)
         g = self.grid
         q = self._raw_fields
         ptrs = _lib.ptr_array([f.ptr for f in q])
@@ -285,7 +316,7 @@ class ShallowWaterModel:
             else:
                 self._substep(dt, stage)
             self.Gn, self.Gm = self.Gm, self.Gn          # store_tendencies!: G⁻ <- Gⁿ (pointer swap, 0 bytes)
-            if not (self._rwrap & _lib.WRAP_X):
+            if any(self._bounded) or not (self._rwrap & _lib.WRAP_X):
                 self._fill_x()                           # (otherwise the next stage reads the periodic images itself)
             else:
                 self._halo_stale = True
@@ -354,7 +385,7 @@ class ShallowWaterModel:
     def _driver_steps(self, dt, n):
         if self._ring is not None:
             return self._ring_steps(dt, n)
-        if not self.decomp.ring and self.fused and self.tendency_events is None:
+        if not self.decomp.ring and self.fused and self.tendency_events is None and not any(self._bounded):
             gr = self.grid
             import ctypes
             swapped = ctypes.c_int(0)

@@ -27,7 +27,8 @@ def test_header_symbols_are_exported(swmhd):
 
 def test_version_and_strerror(swmhd):
     L = swmhd._lib.lib()
-    assert L.swmhd_version() == 100
+    assert L.swmhd_version() == 200
+    assert b"RCCL" in L.swmhd_strerror(4)
     assert b"success" in L.swmhd_strerror(0)
     assert b"halo" in L.swmhd_strerror(2)
 
@@ -48,6 +49,30 @@ def test_argument_validation_without_gpu(swmhd):
     assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 0, 0, 3, 2, 0, None) == 1  # j_begin > j_end
     assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 7, 0, 0, 4, 0, None) == 1  # unknown topology code
     assert g(p, p, p, p, 4, 4, 3, 3, 10, 1.0, 1.0, 0, 0, 2, 2, 0, None) == 0  # empty row range is a no-op
+    # tendency entry points: topology flags
+    t = L.swmhd_tendencies_f64
+    B = swmhd._lib
+    args = (p,) * 8 + (4, 4, 3, 3, 10, 1.0, 1.0, 9.81, 1.0, 1, 1, 0, 4)
+    assert t(*args, B.BOUNDED_X | B.WRAP_X, None) == 1                         # a direction is Bounded or wrapped, not both
+    assert t(*args, B.BOUNDED_Y | B.MARCH_KERNEL, None) == 3                   # walls: LDS-tiled kernel only (SWMHD_ENOTSUP)
+    assert t(*args[:-2], 2, 2, B.BOUNDED_Y, None) == 0                          # empty row range
+    arr = (ctypes.c_void_p * 4)(p, p, p, p)
+    assert L.swmhd_step_rk3_f64(arr, arr, arr, arr, 4, 4, 3, 3, 10, 1.0, 1.0, 9.81, 1.0, 1, 1, 0.1, 1, B.BOUNDED_X, None, None) == 3
+    h = L.swmhd_fill_halo_f64
+    assert h(arr, 4, 4, 4, 3, 3, 10, 0, 5, 1, 2, None, 1.0, 1.0, None) == 1    # unknown topology code
+    assert h(arr, 5, 4, 4, 3, 3, 10, 0, 1, 1, 2, None, 1.0, 1.0, None) == 1    # more than 4 fields
+    assert h(arr, 4, 2, 4, 3, 3, 10, 1, 1, 1, 2, None, 1.0, 1.0, None) == 2    # Nx < Hx
+
+
+def test_geometry_query(swmhd):
+    """swmhd_tendency_launch_geometry: bench.py derives the VALU floor from it.  No GPU needed (the CU count falls back to 256)."""
+    g = swmhd._lib.tendency_launch_geometry(4096, 4096, 1, 8, 0)
+    assert g["kind"] == 2 and g["threads"] == 256 and g["nstrips"] == 17 and g["nstrips"] * 250 >= 4096
+    assert g["nseg"] * g["rows_per_segment"] >= 4096 and (g["nseg"] - 1) * g["rows_per_segment"] < 4096
+    small = swmhd._lib.tendency_launch_geometry(128, 128, 1, 8, 0)
+    assert small["kind"] == 1
+    n1024 = swmhd._lib.tendency_launch_geometry(1024, 1024, 1, 8, 0)
+    assert n1024["threads"] == 128 and n1024["nstrips"] == 9        # 9 x 128 lanes instead of 5 x 256
 
 
 def test_grid_mirror(swmhd):
