@@ -140,8 +140,10 @@ int swmhd_fill_halo_periodic_multi_f32(float *const *fields, int nfields, int Nx
  * the commented boundary conditions SWMHD_example.jl:18-19 / divergence_sw_mhd.jl:17 put GradientBoundaryCondition(-0.05) on the
  * north and south sides of A).  Periodic directions: as swmhd_fill_halo_periodic.  Bounded directions (Oceananigans' defaults):
  *   field at Center in that direction : no-flux -- halo point m mirrors interior point m;  with a gradient value g (not NaN) instead:
- *                                       ONLY the first halo point, c[0] = c[1] - g*d, c[N+1] = c[N] + g*d (as the library fills it)
+ *                                       the first halo point c[0] = c[1] - g*d, c[N+1] = c[N] + g*d (all the library fills)
  *   field at Face in that direction   : impenetrable wall -- c[1] = 0 and c[N+1] = 0 (the first halo line holds the far wall)
+ * Halo points the library never writes (points 2..H of a gradient side, everything beyond a wall of a face field) stay at their
+ * allocation zeros for a whole Oceananigans run; this call sets them to zero, so nothing depends on stale memory.
  * West/east first, then south/north over the padded width.  fields: HOST array of nf (1..4) parents; face_x / face_y: bit f set =
  * field f is located at Face in x / y; gradient: HOST array of 4*nf values (west, east, south, north per field; NaN = default),
  * or NULL.  Two launches.

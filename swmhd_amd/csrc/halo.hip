@@ -1,8 +1,7 @@
 // Periodic halo fill: the stand-alone engine's counterpart of Oceananigans' fill_halo_regions! for
 // topology = (Periodic, Periodic, Flat) (reference: jacobian_formulation/SWMHD_example.jl:16).
 #include "common.hpp"
-// (gradient boundary values are formed as c - g*d in two roundings, like the oracle: no FMA contraction in this file)
-#pragma clang fp contract(off)
+// (gradient boundary values are formed as c - g*d in two roundings, like the oracle: the Makefile builds this file -ffp-contract=off)
 
 namespace swmhd {
 namespace {
@@ -85,11 +84,12 @@ __global__ void k_halo_bc(HaloBc<T> a) {
     auto at = [&](int k) -> T & { return DIR == 0 ? f[(long)line * a.sy + k] : f[(long)k * a.sy + (line - a.Hx)]; };
     if (topo == 0) {
         for (int m = 1; m <= H; ++m) { at(-m) = at(N - m); at(N + m - 1) = at(m - 1); }
-    } else if (face) {
-        at(0) = T(0); at(N) = T(0);                         // impenetrable walls: Julia indices 1 and N+1
-    } else {
-        if (glo == glo) at(-1) = at(0) - glo * d; else for (int m = 1; m <= H; ++m) at(-m) = at(m - 1);
-        if (ghi == ghi) at(N) = at(N - 1) + ghi * d; else for (int m = 1; m <= H; ++m) at(N + m - 1) = at(N - m);
+    } else if (face) {                                      // impenetrable walls at Julia indices 1 and N+1; zeros beyond them
+        at(0) = T(0);
+        for (int m = 1; m <= H; ++m) { at(-m) = T(0); at(N + m - 1) = T(0); }
+    } else {                                                // gradient side: first halo point extrapolated, the others zero
+        for (int m = 1; m <= H; ++m) at(-m) = (glo == glo) ? (m == 1 ? at(0) - glo * d : T(0)) : at(m - 1);
+        for (int m = 1; m <= H; ++m) at(N + m - 1) = (ghi == ghi) ? (m == 1 ? at(N - 1) + ghi * d : T(0)) : at(N - m);
     }
 }
 

@@ -46,15 +46,16 @@ def test_fill_halo_semantics(oracle):
     for m in range(1, H + 1):
         assert np.array_equal(a[H - m, :], a[H + m - 1, :]) and np.array_equal(a[H + Ny + m - 1, :], a[H + Ny - m, :])
     assert np.array_equal(a[I], base[I]) and np.array_equal(a[H:H + Ny, :H], a[H:H + Ny, Nx:Nx + H])
-    # wall-normal velocity, Bounded y: zero ON the walls (Julia j = 1 and Ny+1), nothing beyond is touched
+    # wall-normal velocity, Bounded y: zero ON the walls (Julia j = 1 and Ny+1) and beyond them (what the library never writes keeps
+    # its allocation zeros there; the engine sets it)
     a = O.fill_halo(base.copy(), Nx, Ny, H, H, topo=(P, B), face=(False, True))
-    assert np.all(a[H, :] == 0) and np.all(a[H + Ny, :] == 0)
-    assert np.array_equal(a[:H, H:H + Nx], base[:H, H:H + Nx]) and np.array_equal(a[H + Ny + 1:, H:H + Nx], base[H + Ny + 1:, H:H + Nx])
-    # GradientBoundaryCondition: ONLY the first halo point, linearly extrapolated (the reference's A_bcs: -0.05 north and south)
+    assert np.all(a[:H + 1, :] == 0) and np.all(a[H + Ny:, :] == 0)
+    assert np.array_equal(a[H + 1:H + Ny, H:H + Nx], base[H + 1:H + Ny, H:H + Nx])
+    # GradientBoundaryCondition: the first halo point linearly extrapolated (the reference's A_bcs: -0.05 north and south), zeros beyond
     g, dy = -0.05, 0.3
     a = O.fill_halo(base.copy(), Nx, Ny, H, H, topo=(P, B), grad=(None, None, g, g), dy=dy)
     assert np.array_equal(a[H - 1, :], a[H, :] - g * dy) and np.array_equal(a[H + Ny, :], a[H + Ny - 1, :] + g * dy)
-    assert np.array_equal(a[:H - 1, H:H + Nx], base[:H - 1, H:H + Nx]) and np.array_equal(a[H + Ny + 1:, H:H + Nx], base[H + Ny + 1:, H:H + Nx])
+    assert np.all(a[:H - 1, :] == 0) and np.all(a[H + Ny + 1:, :] == 0)
     # a linear profile A = g*y is reproduced exactly in that first halo point
     yc = (np.arange(-H, Ny + H) + 0.5) * dy
     lin = np.repeat((g * yc)[:, None], Nx + 6, axis=1)
