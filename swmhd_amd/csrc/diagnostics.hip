@@ -4,12 +4,14 @@
 //   kinetic/magnetic/potential/total_energy_func   jacobian_formulation/SWMHD_example.jl:67-77, :87-92
 //                                                  divergence_formulation/divergence_sw_mhd.jl:63-74, :85-91
 //   progress callback max|u|, max|A|, min h        SWMHD_example.jl:47-65
-// Definitions used here (cell-centred, 2nd order; the exact interpolation placement inside Oceananigans' AbstractOperations
-// is library-internal and unpinned -- the committed energy plots are reproduced to plot accuracy, tests/test_diagnostics*):
-//   KE = sum_ij 1/2 h (ℑxᶜ(u²) + ℑyᶜ(v²)) dx dy          (conservative: u = uh/ℑxᶠh, v = vh/ℑyᶠh)
-//   ME = sum_ij 1/2 (ℑxᶜ((∂xA)²/ℑxᶠh) + ℑyᶜ((∂yA)²/ℑyᶠh)) dx dy     [= 1/2 h |B|², B = ẑ×∇A / h]
-//   PE = sum_ij 1/2 g (h − h_ref)² dx dy
-//   max|u|, max|v|, max|A|, min h over the interior
+// Definitions: the reference's expressions evaluated the way Oceananigans' AbstractOperations place them -- a binary operation of
+// two fields at different locations is located where its FIRST operand is, the second is interpolated there (ℑ); a division by a
+// field interpolates the divisor (library-internal and unpinned, like A9):
+//   Jacobian driver    KE = Σ ½ h · ℑxᶜ[u² + ℑxyᶠᶜ(v²)] Δx Δy                       mean((1/2)*h*(u^2 + v^2))*Lx*Ly          SWMHD_example.jl:74
+//   divergence driver  KE = Σ ½ (1/h) · ℑxᶜ[uh² + ℑxyᶠᶜ(vh²)] Δx Δy                 mean((1/2)*(1/h)*(uh^2 + vh^2))*Lx*Ly   divergence_sw_mhd.jl:71
+//   both               ME = Σ ½ h · ℑyᶜ[Bx² + ℑxyᶜᶠ(By²)] Δx Δy,  Bx = −∂yA/ℑyᶠh @cfc, By = ∂xA/ℑxᶠh @fcc   (:69-70,:72 / :67-68,:75)
+//                      PE = Σ ½ g (h − hᵢ)² Δx Δy                                                                             (:73 / :76)
+//   max|u|, max|v| (divergence driver: u = uh/ℑxᶠh, v = vh/ℑyᶠh), max|A|, min h over the interior                                                            SWMHD_example.jl:47-65
 // Two deterministic stages: per-workgroup partials (fixed grid), then one workgroup folds them in index order.
 #include "common.hpp"
 
@@ -66,13 +68,26 @@ __global__ __launch_bounds__(NT) void k_diag_partial(DiagArgs<T> a) {
         auto H = [&](int di, int dj) -> double { return (double)a.h[o + dj * a.sy + di]; };
         auto AA = [&](int di, int dj) -> double { return (double)a.A[o + dj * a.sy + di]; };
         const double hc = H(0, 0);
-        const double hw = 0.5 * (H(-1, 0) + hc), he = 0.5 * (hc + H(1, 0)), hs = 0.5 * (H(0, -1) + hc), hn = 0.5 * (hc + H(0, 1));
-        double uw = Q1(0, 0), ue = Q1(1, 0), vs = Q2(0, 0), vn = Q2(0, 1);
-        if (a.form == 0) { uw /= hw; ue /= he; vs /= hs; vn /= hn; }   // velocities from transports
-        const double ke = 0.5 * hc * (0.5 * (uw * uw + ue * ue) + 0.5 * (vs * vs + vn * vn));
-        const double axw = (AA(0, 0) - AA(-1, 0)) * rdx, axe = (AA(1, 0) - AA(0, 0)) * rdx;
-        const double ays = (AA(0, 0) - AA(0, -1)) * rdy, ayn = (AA(0, 1) - AA(0, 0)) * rdy;
-        const double me = 0.5 * (0.5 * (axw * axw / hw + axe * axe / he) + 0.5 * (ays * ays / hs + ayn * ayn / hn));
+        // kinetic energy: W(i) = q1² + ℑxyᶠᶜ(q2²) at the faces i and i+1, then ℑxᶜ
+        auto W = [&](int di) -> double {
+            const double p = Q1(di, 0);
+            const double g00 = Q2(di - 1, 0), g10 = Q2(di, 0), g01 = Q2(di - 1, 1), g11 = Q2(di, 1);
+            return p * p + 0.5 * (0.5 * (g00 * g00 + g10 * g10) + 0.5 * (g01 * g01 + g11 * g11));
+        };
+        const double wbar = 0.5 * (W(0) + W(1));
+        const double ke = a.form == 0 ? 0.5 * (1.0 / hc) * wbar : 0.5 * hc * wbar;
+        // magnetic energy: Z(j) = Bx² + ℑxyᶜᶠ(By²) at the faces j and j+1, then ℑyᶜ
+        auto BX = [&](int di, int dj) -> double { return -((AA(di, dj) - AA(di, dj - 1)) * rdy) / (0.5 * (H(di, dj - 1) + H(di, dj))); };
+        auto BY = [&](int di, int dj) -> double { return ((AA(di, dj) - AA(di - 1, dj)) * rdx) / (0.5 * (H(di - 1, dj) + H(di, dj))); };
+        auto Z = [&](int dj) -> double {
+            const double b = BX(0, dj);
+            const double c00 = BY(0, dj - 1), c10 = BY(1, dj - 1), c01 = BY(0, dj), c11 = BY(1, dj);
+            return b * b + 0.5 * (0.5 * (c00 * c00 + c10 * c10) + 0.5 * (c01 * c01 + c11 * c11));
+        };
+        const double me = 0.5 * hc * (0.5 * (Z(0) + Z(1)));
+        // progress callback: maximum(abs, u) with u = uh / h located at uh's faces (divergence_sw_mhd.jl:45-47,53); u itself for the Jacobian driver
+        double uw = Q1(0, 0), vs = Q2(0, 0);
+        if (a.form == 0) { uw /= 0.5 * (H(-1, 0) + hc); vs /= 0.5 * (H(0, -1) + hc); }
         const double dh = hc - (double)a.href;
         const double pe = 0.5 * (double)a.grav * dh * dh;
         const double v[NQ] = {ke, me, pe, fabs(uw), fabs(vs), fabs(AA(0, 0)), hc};

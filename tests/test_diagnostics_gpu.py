@@ -11,20 +11,24 @@ G = 9.81
 
 
 def np_diagnostics(q1, q2, h, A, g, form, href=1.0):
-    """numpy evaluation of the formulas documented in swmhd_amd/csrc/diagnostics.hip (test-side restatement)."""
+    """numpy evaluation of the formulas documented in swmhd_amd/csrc/diagnostics.hip (test-side restatement): the reference's
+    energy expressions with Oceananigans' operand-location rule -- KE: SWMHD_example.jl:74 (form 1) / divergence_sw_mhd.jl:71 (form 0,
+    literally (1/2)(1/h)(uh^2 + vh^2)); ME: :75 / :72 with B_x = -dA/dy / h, B_y = dA/dx / h (:69-70 / :67-68)."""
     H, Nx, Ny = g.Hx, g.Nx, g.Ny
     S = lambda a, di, dj: a[H + dj:H + dj + Ny, H + di:H + di + Nx]
     hc = S(h, 0, 0)
-    hw, he, hs, hn = 0.5 * (S(h, -1, 0) + hc), 0.5 * (hc + S(h, 1, 0)), 0.5 * (S(h, 0, -1) + hc), 0.5 * (hc + S(h, 0, 1))
-    uw, ue, vs, vn = S(q1, 0, 0), S(q1, 1, 0), S(q2, 0, 0), S(q2, 0, 1)
-    if form == 0:
-        uw, ue, vs, vn = uw / hw, ue / he, vs / hs, vn / hn
-    ke = 0.5 * hc * (0.5 * (uw ** 2 + ue ** 2) + 0.5 * (vs ** 2 + vn ** 2))
-    axw, axe = (S(A, 0, 0) - S(A, -1, 0)) / g.dx, (S(A, 1, 0) - S(A, 0, 0)) / g.dx
-    ays, ayn = (S(A, 0, 0) - S(A, 0, -1)) / g.dy, (S(A, 0, 1) - S(A, 0, 0)) / g.dy
-    me = 0.5 * (0.5 * (axw ** 2 / hw + axe ** 2 / he) + 0.5 * (ays ** 2 / hs + ayn ** 2 / hn))
+    W = lambda di: S(q1, di, 0) ** 2 + 0.5 * (0.5 * (S(q2, di - 1, 0) ** 2 + S(q2, di, 0) ** 2) + 0.5 * (S(q2, di - 1, 1) ** 2 + S(q2, di, 1) ** 2))
+    wbar = 0.5 * (W(0) + W(1))
+    ke = 0.5 * (1.0 / hc) * wbar if form == 0 else 0.5 * hc * wbar
+    BX = lambda di, dj: -((S(A, di, dj) - S(A, di, dj - 1)) / g.dy) / (0.5 * (S(h, di, dj - 1) + S(h, di, dj)))
+    BY = lambda di, dj: ((S(A, di, dj) - S(A, di - 1, dj)) / g.dx) / (0.5 * (S(h, di - 1, dj) + S(h, di, dj)))
+    Z = lambda dj: BX(0, dj) ** 2 + 0.5 * (0.5 * (BY(0, dj - 1) ** 2 + BY(1, dj - 1) ** 2) + 0.5 * (BY(0, dj) ** 2 + BY(1, dj) ** 2))
+    me = 0.5 * hc * (0.5 * (Z(0) + Z(1)))
     pe = 0.5 * G * (hc - href) ** 2
     c = g.dx * g.dy
+    uw, vs = S(q1, 0, 0), S(q2, 0, 0)
+    if form == 0:      # u = uh / h at uh's faces (divergence_sw_mhd.jl:45-47)
+        uw, vs = uw / (0.5 * (S(h, -1, 0) + hc)), vs / (0.5 * (S(h, 0, -1) + hc))
     return dict(kinetic_energy=ke.sum() * c, magnetic_energy=me.sum() * c, potential_energy=pe.sum() * c,
                 max_abs_u=np.abs(uw).max(), max_abs_v=np.abs(vs).max(), max_abs_A=np.abs(S(A, 0, 0)).max(), min_h=hc.min())
 
