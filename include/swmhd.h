@@ -250,7 +250,7 @@ int swmhd_step_rk3_f32(float *const *q, float *const *q_alt, float *const *Ga, f
 
 /* Launch geometry the fast tendency entry points use for an Nx x rows launch on the current device (introspection for
  * benchmarks: bench.py derives the kernel's fp64-VALU floor from it; nothing in the reference corresponds to it).
- * out[0] = kernel kind (1 LDS-tiled, 2 row-marching), out[1] = threads per workgroup, out[2] = strips (workgroups along x),
+ * out[0] = kernel kind (1 LDS-tiled, 2 row-marching, 3 row-marching with two fp32 columns per lane), out[1] = threads per workgroup, out[2] = strips (workgroups along x),
  * out[3] = segments (workgroups along y), out[4] = rows per segment, out[5] = resident workgroups per CU the kernel is built
  * for, out[6] = halo lanes per strip side, out[7] = compute units of the device.  elem_size 8 (f64) or 4 (f32); flags as above. */
 int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int flags, int out[8]);

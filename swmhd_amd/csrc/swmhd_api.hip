@@ -229,7 +229,7 @@ int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_s
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;
     const int variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : 0);
     return tendency_launch_geometry(Nx, rows, formulation, elem_size, (flags & SWMHD_STRICT) ? 1 : variant, (flags & SWMHD_LEAVE_ROOM) ? 1 : 0,
-                                    (flags & (SWMHD_WRAP_X | SWMHD_WRAP_Y)) ? 1 : 0, out);
+                                    ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0), out);
 }
 
 #define SWMHD_DEF_LORENTZ(sfx, T)                                                                                      \

@@ -461,3 +461,43 @@ def test_byte_offsets_beyond_2GiB(swmhd, form):
     for a, b in zip(*res):      # (dx = 3.8e-4 amplifies rounding in the gradients: an addressing error would be O(1), not 1e-11)
         assert torch.isfinite(a).all()
         assert (a - b).abs().max().item() <= 2e-11 * max(b.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("lor", [1, 0])
+@pytest.mark.parametrize("shape", [(512, 40), (1000, 64), (1024, 256), (600, 70), (2048, 33)])
+def test_packed_fp32_marching_kernel(swmhd, oracle, lor, shape):
+    """Config 5's fp32 leg runs on k_tendency_vi_march_pk (two columns per lane, v_pk_* arithmetic; taken when x is read with periodic
+    wrapping and Nx is even).  Same bars as the unpacked fp32 kernel: tendencies within 1e-4 max-norm of the fp32 oracle; and it agrees
+    with the unpacked kernel (model with fuse_halo=False: no SWMHD_WRAP_X, so the launcher keeps one column per lane) to fp32 rounding,
+    for a tendency evaluation and for three fused RK3 steps (all stage variants: first / with G- / last)."""
+    Nx, Ny = shape
+    q = random_state(Nx, Ny, 3, 5 + Nx, 1, dtype=np.float32)
+    dx, dy = 0.11, 0.13
+    want = oracle.tendencies(*q, Nx, Ny, 3, 3, dx, dy, 1, lor, G, F, nthreads=8)
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, dx * Nx), y=(0, dy * Ny), halo=(3, 3))
+    assert swmhd._lib.tendency_launch_geometry(Nx, Ny, 1, 4, swmhd._lib.MARCH_KERNEL | swmhd._lib.WRAP_X)["kind"] == 3
+    assert swmhd._lib.tendency_launch_geometry(Nx, Ny, 1, 4, swmhd._lib.MARCH_KERNEL)["kind"] == 2
+    ms = []
+    for fuse_halo in (True, False):
+        m = swmhd.ShallowWaterModel(g, G, F, formulation="VectorInvariant", lorentz_forcing=bool(lor), dtype=torch.float32,
+                                    kernel="march", fuse_halo=fuse_halo)
+        for f, a in zip(m._raw_fields, q):
+            f.data.copy_(torch.from_numpy(a))
+        for g_ in m.Gn:
+            g_.data.fill_(-3.25)
+        m.calculate_tendencies(); torch.cuda.synchronize()
+        ms.append(m)
+    I = g.interior
+    for w, gp, gu in zip(want, ms[0].Gn, ms[1].Gn):
+        ref = np.abs(w[I]).max()
+        assert np.abs(w[I] - gp.numpy()[I]).max() <= 1e-4 * ref
+        assert np.abs(gu.numpy()[I] - gp.numpy()[I]).max() <= 2e-5 * ref
+        halo = gp.data.clone(); halo[I] = -3.25
+        assert torch.all(halo == -3.25), "packed kernel wrote outside the interior"
+    for m in ms:
+        for _ in range(3):
+            m.time_step(1e-3)
+        m.synchronize()
+    for a, b in zip(ms[0].fields, ms[1].fields):
+        assert (a.data[I] - b.data[I]).abs().max().item() <= 2e-5 * max(b.data[I].abs().max().item(), 1.0)
+        assert torch.isfinite(a.data).all()
