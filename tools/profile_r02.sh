@@ -14,6 +14,8 @@ step 400 $O/valu_bench.json rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 
 step 400 $O/wait_bench.json rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_wait -o wait --output-format csv -- $BENCH --steps 3 --warmup 1
 step 400 $O/fetch_bench.json rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o fetch --output-format csv -- $BENCH --steps 3 --warmup 1
 step 400 $O/write_bench.json rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o write --output-format csv -- $BENCH --steps 3 --warmup 1
+# operator kernels (the reference's own hot path): kernel trace of tools/time_ops.py
+step 400 $O/ops_time.log rocprofv3 --kernel-trace --stats -d $O/ops -o ops --output-format csv -- python3 $R/tools/time_ops.py 4096
 find $O -name "*.csv" | head -30
 # keep the merge-back small: the per-dispatch trace of the 100-step run is the only big file
 find $O -name "*kernel_trace.csv" -size +20M -delete

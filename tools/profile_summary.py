@@ -82,15 +82,25 @@ def main():
             out["tendency_stage_mean_ms"] = mean([d for _, d, _ in timed]) / 1e3
             out["tendency_stage_mean_ms_by_stage"] = {MODE_STAGE[m]: mean([d for _, d, mm in timed if mm == m]) / 1e3 for m in ("5", "7", "3")}
             out["tendency_stage_mean_note"] = f"mean over the last {len(timed)} fused-stage dispatches (= the timed region of the run)"
-        for k in ("k_lorentz_jacobian_march", "k_lorentz_divergence_march"):
-            if k in out["kernels"]:
-                out[k + "_mean_ms"] = out["kernels"][k]["mean_us"] / 1e3
         json.dump(out, open(os.path.join(a.out, "fullstep_kernel_stats.json"), "w"), indent=1)
-        json.dump({kk: out[kk] for kk in out if kk.endswith("_mean_ms") or kk in ("kernel_source_hash", "git_head", "command", "collected_by")},
-                  open(os.path.join(a.out, "operators_kernel_stats.json"), "w"), indent=1)
         bj = os.path.join(a.raw, "stats_bench.json")
         if os.path.exists(bj):
             shutil.copy(bj, os.path.join(a.out, "fullstep_bench_under_rocprof.json"))
+
+    # ---- operator kernels: kernel trace of tools/time_ops.py 4096 (300 spin-up + 30 timed launches per kernel)
+    so = os.path.join(a.raw, "ops", "ops_kernel_stats.csv")
+    if os.path.exists(so):
+        shutil.copy(so, os.path.join(a.out, "operators_kernel_stats.csv"))
+        out = {"command": "rocprofv3 --kernel-trace --stats -- python3 tools/time_ops.py 4096", **provenance("tools/profile_r02.sh + tools/profile_summary.py")}
+        for r in csv.DictReader(open(so)):
+            k, _ = kernel_key(r["Name"])
+            if k and k.startswith("k_lorentz"):
+                out[k + "_mean_ms"] = float(r["AverageNs"]) / 1e6
+                out[k + "_calls"] = int(r["Calls"])
+        json.dump(out, open(os.path.join(a.out, "operators_kernel_stats.json"), "w"), indent=1)
+        lg = os.path.join(a.raw, "ops_time.log")
+        if os.path.exists(lg):
+            shutil.copy(lg, os.path.join(a.out, "operators_timing_under_rocprof.txt"))
 
     # ---- VALU instruction counts per wave-row
     pv = os.path.join(a.raw, "pmc_valu", "valu_counter_collection.csv")
