@@ -284,7 +284,7 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: global grid {Nx}x{Ny_global} ({Nx}x{Ny_local} cells per GPU), periodic, "
                                    f"{form} formulation + {lor}-form Lorentz forcing, {CONFIGS[args.config]['text']}",
-                       "step": "one RK3 time step = 3 x (fused tendency+substep kernel, halo fill of 4 fields)",
+                       "step": "one RK3 time step = 3 fused tendency+substep launches (periodic images gathered on read: no halo launch between stages)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
                        "spin_up": "40 untimed steps before the warm-up steps (device clocks settle after ~30 ms of load)",
                        "decomposition": (f"y-slabs x{world} (ring halo exchange, backend {args.backend}, overlapped; "

@@ -13,10 +13,14 @@
 module SWMHDAmd
 
 using Oceananigans, AMDGPU
+using Oceananigans.Grids: topology
 
 const libswmhd = get(ENV, "SWMHD_LIB", joinpath(@__DIR__, "..", "swmhd_amd", "libswmhd.so"))
 
 const SWMHD_FAST, SWMHD_STRICT = Cint(0), Cint(1)
+const SWMHD_WRAP_X, SWMHD_WRAP_Y = Cint(16), Cint(32)            # read periodic images instead of halo cells (no halo launch per stage)
+const SWMHD_BOUNDED_X, SWMHD_BOUNDED_Y = Cint(256), Cint(512)    # Grids.topology(grid, d) == Bounded
+const SWMHD_PERIODIC, SWMHD_BOUNDED = Cint(0), Cint(1)
 const CONSERVATIVE, VECTOR_INVARIANT = Cint(0), Cint(1)
 const LORENTZ_NONE, LORENTZ_JACOBIAN, LORENTZ_DIVERGENCE = Cint(0), Cint(1), Cint(2)
 
@@ -70,7 +74,9 @@ end
     native_steps!(q, q_alt, Ga, Gb, grid, Δt, n; formulation, lorentz) -> state_in_alt::Bool
 
 Hand `n` whole RK3 steps to the engine (swmhd_step_rk3_f64): q, q_alt are 4-tuples of fields (u|uh, v|vh, h, A) -- current state
-and a scratch copy --, Ga, Gb two 4-tuples of tendency fields.  Periodic single-GPU grids.  The base right-hand side inside is a
+and a scratch copy --, Ga, Gb two 4-tuples of tendency fields.  Periodic single-GPU grids.  With `flags = SWMHD_WRAP_X | SWMHD_WRAP_Y`
+no halo launch runs between the stages (3 launches per step); the halos of the returned state are then stale: `fill_halos!` before
+anything else reads them.  The base right-hand side inside is a
 restatement of Oceananigans' scheme that could not be checked against the library (DESIGN.md section 3).
 """
 function native_steps!(q, q_alt, Ga, Gb, grid, Δt, n; formulation = VECTOR_INVARIANT, lorentz = LORENTZ_JACOBIAN, g = 9.81, f = 1.0,
@@ -94,6 +100,48 @@ function diagnostics(q, grid; formulation = VECTOR_INVARIANT, g = 9.81, h_ref = 
                 pp(q[1]), pp(q[2]), pp(q[3]), pp(q[4]), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]), grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ,
                 g, h_ref, formulation, 0, grid.Ny, pointer(ws), pointer(out), hipstream()))
     return Array(out)
+end
+
+"Topology flags of a grid for the tendency entry points (the reference tests `topology(grid, d) == Bounded`, sw_mhd_divergence_functions.jl:42)."
+topology_flags(grid) = (topology(grid, 1) == Bounded ? SWMHD_BOUNDED_X : Cint(0)) | (topology(grid, 2) == Bounded ? SWMHD_BOUNDED_Y : Cint(0))
+
+"""
+    fill_halos!(q, grid; A_gradients = (NaN, NaN, NaN, NaN))
+
+fill_halo_regions! of the four prognostic fields (u|uh, v|vh, h, A) for any (Periodic | Bounded) topology pair with Oceananigans' default
+boundary conditions; `A_gradients` = (west, east, south, north) GradientBoundaryCondition values of A (NaN = default), e.g. the
+reference's commented `A_bcs` (SWMHD_example.jl:18-19): `(NaN, NaN, -0.05, -0.05)`.  swmhd_fill_halo_f64.
+"""
+function fill_halos!(q, grid; A_gradients = (NaN, NaN, NaN, NaN))
+    ptrs = Ptr{Float64}[pp(x) for x in q]
+    grad = vcat(fill(NaN, 12), collect(Float64, A_gradients))            # fields 0..2 default, field 3 = A
+    tx = topology(grid, 1) == Bounded ? SWMHD_BOUNDED : SWMHD_PERIODIC
+    ty = topology(grid, 2) == Bounded ? SWMHD_BOUNDED : SWMHD_PERIODIC
+    check(ccall((:swmhd_fill_halo_f64, libswmhd), Cint,
+                (Ptr{Ptr{Float64}}, Cint, Cint, Cint, Cint, Cint, Int64, Cint, Cint, Cint, Cint, Ptr{Float64}, Float64, Float64, Ptr{Cvoid}),
+                ptrs, 4, grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]), tx, ty,
+                0b0001 #= field 0 (u|uh) is at Face in x =#, 0b0010 #= field 1 (v|vh) is at Face in y =#, grad,
+                grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, hipstream()))
+end
+
+"""
+    native_stage!(q, qnew, Gn, Gm, grid, Δt, γ, ζ, store_G; ...)
+
+ONE fused RK3 stage (calculate_tendencies! + rk3_substep!, swmhd_tendencies_rk3_f64) on any topology: the caller swaps q <-> qnew and
+Gn <-> Gm afterwards and, in Bounded directions, calls `fill_halos!`; Periodic directions need no halo fill when `flags` carry
+SWMHD_WRAP_X / SWMHD_WRAP_Y (the kernels read the periodic images themselves).  `Gm === nothing` on the first stage.
+"""
+function native_stage!(q, qnew, Gn, Gm, grid, Δt, γ, ζ, store_G; formulation = VECTOR_INVARIANT, lorentz = LORENTZ_JACOBIAN, g = 9.81, f = 1.0,
+                       flags = SWMHD_FAST)
+    ptrs(t) = Ptr{Float64}[pp(x) for x in t]
+    fl = flags | topology_flags(grid)
+    topology(grid, 1) == Periodic && (fl |= SWMHD_WRAP_X)
+    topology(grid, 2) == Periodic && (fl |= SWMHD_WRAP_Y)
+    check(ccall((:swmhd_tendencies_rk3_f64, libswmhd), Cint,
+                (Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Cint, Cint, Cint, Cint, Int64,
+                 Float64, Float64, Float64, Float64, Cint, Cint, Float64, Float64, Float64, Cint, Cint, Cint, Cint, Ptr{Cvoid}),
+                ptrs(q), ptrs(qnew), ptrs(Gn), Gm === nothing ? C_NULL : ptrs(Gm), grid.Nx, grid.Ny, grid.Hx, grid.Hy, stride_y(q[1]),
+                grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, g, f, formulation, lorentz, Δt, γ, ζ, store_G ? 1 : 0, 0, grid.Ny, fl, hipstream()))
 end
 
 # ---- several GPUs: one Julia process per GPU (e.g. MPI.jl), the domain cut into y-slabs -----------------------------------
