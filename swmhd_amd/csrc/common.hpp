@@ -62,6 +62,8 @@ struct TendArgs {
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
+    int drop_G;           // marching kernels: issue the G stores with an out-of-range offset (the hardware drops them): lets the last RK3
+                          // stage run the stage-2 kernel variant where that one has the better register allocation
     int wrap;             // periodic index wrapping of the READS: bit0 = x, bit1 = y -- the kernel takes (x mod Nx, y mod Ny) instead of the
                           // halo cells, so the caller need not have filled those halos (no halo-fill launch between RK3 stages)
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel

@@ -115,7 +115,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.G1 = G1 + off; a.G2 = G2 + off; a.Gh = Gh + off; a.GA = GA + off;
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
-    a.fuse = 0; a.first = 0; a.store_G = 1; a.dt = a.gamma = a.zeta = T(0);
+    a.fuse = 0; a.first = 0; a.store_G = 1; a.drop_G = 0; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
     a.topo_x = (flags & SWMHD_BOUNDED_X) ? SWMHD_BOUNDED : SWMHD_PERIODIC; a.topo_y = (flags & SWMHD_BOUNDED_Y) ? SWMHD_BOUNDED : SWMHD_PERIODIC;
