@@ -268,6 +268,9 @@ int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_s
  * ---------------------------------------------------------------------------------------------- */
 #define SWMHD_RING_ID_BYTES 128
 typedef struct swmhd_ring swmhd_ring;
+/* SWMHD_OK if the RCCL library can be loaded from rccl_path (SWMHD_ENOTSUP otherwise).  Creates nothing: lets the ranks agree that
+ * every one of them can take the native path BEFORE any of them enters the collective swmhd_ring_create. */
+int swmhd_ring_available(const char *rccl_path);
 int swmhd_ring_unique_id(const char *rccl_path, void *id128);
 int swmhd_ring_create(swmhd_ring **ring, const char *rccl_path, int nranks, int rank, const void *id128);
 int swmhd_ring_destroy(swmhd_ring *ring);

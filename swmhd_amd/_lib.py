@@ -79,6 +79,8 @@ def _declare(lib):
         f.restype = i
     lib.swmhd_tendency_launch_geometry.argtypes = [i, i, i, i, i, C.POINTER(i)]
     lib.swmhd_tendency_launch_geometry.restype = i
+    lib.swmhd_ring_available.argtypes = [C.c_char_p]
+    lib.swmhd_ring_available.restype = i
     lib.swmhd_ring_unique_id.argtypes = [C.c_char_p, p]
     lib.swmhd_ring_unique_id.restype = i
     lib.swmhd_ring_create.argtypes = [C.POINTER(p), C.c_char_p, i, i, p]
@@ -103,7 +105,7 @@ EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] 
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
         "fill_halo", "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
         "ring_exchange_y", "ring_step_rk3")] + [
-    "swmhd_ring_" + name for name in ("unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
+    "swmhd_ring_" + name for name in ("available", "unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
                                       "launch_times")]
 RING_ID_BYTES = 128
 

@@ -210,6 +210,12 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
 
 extern "C" {
 
+int swmhd_ring_available(const char *rccl_path) {
+    RcclApi api;
+    std::string err;
+    return load_rccl(rccl_path, api, err) ? SWMHD_OK : SWMHD_ENOTSUP;
+}
+
 int swmhd_ring_unique_id(const char *rccl_path, void *id128) {
     if (!id128) return SWMHD_EINVAL;
     RcclApi api;

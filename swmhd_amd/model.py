@@ -86,22 +86,27 @@ class ShallowWaterModel:
         dev = self._raw_fields[0].data.device
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")     # the copy torch has loaded
         rccl = rccl.encode() if os.path.exists(rccl) else None
-        ident = torch.zeros(_lib.RING_ID_BYTES, dtype=torch.uint8)
-        if self.decomp.rank == 0:
-            buf = (ctypes.c_ubyte * _lib.RING_ID_BYTES)()
-            rc = self._L.swmhd_ring_unique_id(rccl, buf)
-            if rc == 0:
-                ident = torch.tensor(list(buf), dtype=torch.uint8)
-            else:   # RCCL could not be loaded: every rank learns it from the all-zero id and takes the torch p2p path
+        # The ranks AGREE that every one of them can load RCCL (swmhd_ring_available: dlopen + symbol lookup, creates nothing) before any
+        # of them enters the collective ncclCommInitRank: a rank that cannot must not leave its peers blocked inside communicator creation
+        # -- then all of them take the torch.distributed p2p path instead.
+        rc = self._L.swmhd_ring_available(rccl)
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) == 0:
+            if rc != 0:
                 import sys
                 print(f"swmhd_amd: native ring unavailable ({self._L.swmhd_strerror(rc).decode()}); using torch.distributed p2p",
                       file=sys.stderr)
+            return None
+        ident = torch.zeros(_lib.RING_ID_BYTES, dtype=torch.uint8)
+        if self.decomp.rank == 0:
+            buf = (ctypes.c_ubyte * _lib.RING_ID_BYTES)()
+            _lib.check(self._L.swmhd_ring_unique_id(rccl, buf), "swmhd_ring_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
         ident = ident.to(dev)
         src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
         dist.broadcast(ident, src=src, group=self.group)
         raw = bytes(ident.cpu().tolist())
-        if not any(raw):
-            return None
         ring = ctypes.c_void_p()
         with torch.cuda.device(dev):
             rc = self._L.swmhd_ring_create(ctypes.byref(ring), rccl, self.decomp.world_size, self.decomp.rank,
