@@ -59,6 +59,8 @@ struct TendArgs {
     long sy;
     T dx, dy, rdx, rdy, grav, fcor;
     int j0, j1;
+    int j0b, j1b;         // optional SECOND row range served by the same launch (LDS-tiled kernel; empty when j1b <= j0b): the two
+                          // boundary strips of a y-slab are one launch on the exchange's critical path instead of two
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
@@ -188,6 +190,12 @@ template <typename T> hipError_t launch_tendency_fast(const TendArgs<T> &a, int 
 int tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int kernel_variant, int leave_room, int wrap, int out[8]);
 template <typename T> hipError_t launch_tendency_strict(const TendArgs<T> &a, int formulation, int lorentz, hipStream_t s);
 template <typename T> hipError_t launch_rk3_substep_fast(const Rk3Args<T> &a, hipStream_t s);
+// internal twin of swmhd_tendencies_rk3_* for the slab driver (ring.hip): rows [j0, j1) and [j0b, j1b) of one RK3 stage in ONE launch
+// where the kernel chosen supports it (same argument checks and return codes as the exported call)
+template <typename T>
+int tendencies_rk3_two_ranges(const T *const *q, T *const *qnew, T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy, long sy,
+                              T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, T gamma, T zeta, int store_G, int j0, int j1,
+                              int j0b, int j1b, int flags, void *stream);
 template <typename T> hipError_t launch_rk3_substep_strict(const Rk3Args<T> &a, hipStream_t s);
 
 // energies + extrema; workspace >= SWMHD_DIAG_WORKSPACE doubles, out = 7 doubles (both device memory)

@@ -125,8 +125,11 @@ template <> struct Api<float> {
 
 // nsteps RK3 steps of one y-slab.  Per stage (X = current state, Y = the other buffer set):
 //   main stream : rows [Hy, Ny-Hy) of X -> Y          (need no remote data; the exchange of X is still in flight)
-//   comm stream : ... exchange of X ... ; rows [0,Hy) and [Ny-Hy,Ny) of X -> Y     (queued behind the exchange)
-//   main stream : wait(comm) ; x-halo fill of Y ; record ; comm waits ; comm: exchange of Y    (overlaps the next stage)
+//   comm stream : ... exchange of X ... ; rows [0,Hy) and [Ny-Hy,Ny) of X -> Y     (one launch, queued behind the exchange)
+//   x wrapped on read : comm: exchange of Y straight after the strips ; comm waits for main's interior ; main waits for the strips
+//   x halos in memory : main: wait(comm) ; x-halo fill of Y ; record ; comm waits ; comm: exchange of Y
+// Either way the exchange of Y overlaps the next stage's interior rows.  A thin slab is bound by the chain exchange -> strips ->
+// exchange on the comm stream (tools/ring_rehearsal.py), which is why that chain has no hop through the main stream.
 // The first stage of the first call finds no exchange in flight and the caller's halos current: it runs all rows at once.
 template <typename T>
 int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx, int Ny, int Hx, int Hy, int64_t sy,
@@ -151,6 +154,9 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
     }
     int swaps = 0;
     hipError_t e;
+    // whatever the caller enqueued on its stream so far precedes everything this call puts on the comm stream
+    if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return hipfail(r, "record", e);
+    if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return hipfail(r, "wait", e);
     // Error exit from the middle of a step: whatever was enqueued stays enqueued, so order the caller's stream behind the comm
     // stream and forget the in-flight exchange -- `pending` must never describe an exchange that was not (fully) issued -- and
     // tell the caller which buffer set holds the newest completed stage.
@@ -187,15 +193,26 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
                 else { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
             }
             if (rc) return bail(rc);
-            if (split) {
-                if ((rc = run(0, Hy, c))) return bail(rc);
-                if ((rc = run(Ny - Hy, Ny, c))) return bail(rc);
+            if (split) {   // both strips in one launch: they sit on the exchange -> strips -> exchange chain that bounds a thin slab
+                if ((rc = swmhd::tendencies_rk3_two_ranges<T>(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, (long)sy, dx, dy, grav, fcor, formulation,
+                                                              lorentz, dt, gam[st], zet[st], store, 0, Hy, Ny - Hy, Ny, flags, (void *)c)))
+                    return bail(rc);
                 if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return bail(hipfail(r, "record", e));
                 if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
             }
             for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
             ++swaps;
             r->pending = nullptr;   // the exchange of the OLD state has been consumed; none of the new state is in flight yet
+            if (split && (flags & SWMHD_WRAP_X)) {
+                // The rows the exchange sends are exactly the strips' output and (x wrapped on read) no x-halo kernel touches them:
+                // the exchange of the new state follows the strips on the comm stream directly, without a round trip through the
+                // main stream; only the NEXT stage's strips wait for this stage's interior rows.
+                if ((rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c))) return bail(rc);
+                r->pending = cur[0];
+                if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return bail(hipfail(r, "record", e));
+                if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
+                continue;
+            }
             if (!(flags & SWMHD_WRAP_X) && (rc = Api<T>::halo(cur, 4, Nx, Ny, Hx, Hy, sy, SWMHD_HALO_X, (void *)s))) return bail(rc);
             if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return bail(hipfail(r, "record", e));
             if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));

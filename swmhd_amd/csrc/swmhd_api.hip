@@ -93,11 +93,12 @@ struct FuseRk3 {
 template <typename T>
 int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, T *Gh, T *GA, int Nx, int Ny, int Hx, int Hy,
                 int64_t sy, T dx, T dy, T grav, T fcor, int formulation, int lorentz, int j0, int j1, int flags, void *stream,
-                const FuseRk3<T> *rk = nullptr) {
+                const FuseRk3<T> *rk = nullptr, int j0b = 0, int j1b = 0) {
     if (!q1 || !q2 || !h || !A || !G1 || !G2 || !Gh || !GA) return SWMHD_EINVAL;
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
     if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
+    if (j1b > j0b && (j0b < j1 || j1b > Ny)) return SWMHD_EINVAL;   // (internal: second row range of the slab driver, above the first)
     if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_EINVAL;
     if (((flags & SWMHD_BOUNDED_X) && (flags & SWMHD_WRAP_X)) || ((flags & SWMHD_BOUNDED_Y) && (flags & SWMHD_WRAP_Y))) return SWMHD_EINVAL;
     if ((flags & (SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) && (flags & SWMHD_MARCH_KERNEL)) return SWMHD_ENOTSUP;   // walls: LDS-tiled kernel only
@@ -108,13 +109,14 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
                     (formulation == SWMHD_CONSERVATIVE && lorentz == SWMHD_LORENTZ_DIVERGENCE);
     if (!ok) return SWMHD_EINVAL;
     if (Hx < 3 || Hy < 3) return SWMHD_EHALO;
-    if (j0 == j1) return SWMHD_OK;
+    if (j0 == j1 && j1b <= j0b) return SWMHD_OK;
     TendArgs<T> a;
     const long off = (long)Hy * sy + Hx;
     a.q1 = q1 + off; a.q2 = q2 + off; a.h = h + off; a.A = A + off;
     a.G1 = G1 + off; a.G2 = G2 + off; a.Gh = Gh + off; a.GA = GA + off;
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
+    a.j0b = j1b > j0b ? j0b : 0; a.j1b = j1b > j0b ? j1b : 0;
     a.fuse = 0; a.first = 0; a.store_G = 1; a.drop_G = 0; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
@@ -133,7 +135,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
 template <typename T>
 int tend_rk3_common(const T *const *q, T *const *qnew, T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy, int64_t sy,
                     T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, T gamma, T zeta, int store_G, int j0, int j1,
-                    int flags, void *stream) {
+                    int flags, void *stream, int j0b = 0, int j1b = 0) {
     if (!q || !qnew || !Gn) return SWMHD_EINVAL;
     for (int f = 0; f < 4; ++f) {
         if (!q[f] || !qnew[f] || !Gn[f] || (Gm && !Gm[f])) return SWMHD_EINVAL;
@@ -142,7 +144,7 @@ int tend_rk3_common(const T *const *q, T *const *qnew, T *const *Gn, const T *co
     }
     FuseRk3<T> rk{{qnew[0], qnew[1], qnew[2], qnew[3]}, Gm, dt, gamma, zeta, store_G ? 1 : 0};
     return tend_common<T>(q[0], q[1], q[2], q[3], Gn[0], Gn[1], Gn[2], Gn[3], Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation,
-                          lorentz, j0, j1, flags, stream, &rk);
+                          lorentz, j0, j1, flags, stream, &rk, j0b, j1b);
 }
 
 template <typename T>
@@ -208,6 +210,22 @@ int diag_common(const T *q1, const T *q2, const T *h, const T *A, int Nx, int Ny
 }
 
 }  // namespace
+
+namespace swmhd {
+template <typename T>
+int tendencies_rk3_two_ranges(const T *const *q, T *const *qnew, T *const *Gn, const T *const *Gm, int Nx, int Ny, int Hx, int Hy, long sy,
+                              T dx, T dy, T grav, T fcor, int formulation, int lorentz, T dt, T gamma, T zeta, int store_G, int j0, int j1,
+                              int j0b, int j1b, int flags, void *stream) {
+    return tend_rk3_common<T>(q, qnew, Gn, Gm, Nx, Ny, Hx, Hy, (int64_t)sy, dx, dy, grav, fcor, formulation, lorentz, dt, gamma, zeta,
+                              store_G, j0, j1, flags, stream, j0b, j1b);
+}
+#define SW_INST(T)                                                                                                                   \
+    template int tendencies_rk3_two_ranges<T>(const T *const *, T *const *, T *const *, const T *const *, int, int, int, int, long, T, \
+                                              T, T, T, int, int, T, T, T, int, int, int, int, int, int, void *);
+SW_INST(double)
+SW_INST(float)
+#undef SW_INST
+}  // namespace swmhd
 
 extern "C" {
 

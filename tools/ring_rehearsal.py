@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Ring-of-ONE rehearsal of the multi-GPU step at strong-scaled slab sizes (one GPU: every send goes to self through RCCL, everything
+but the xGMI hop is real): RK3 step time through the native ring driver vs the plain periodic single-GPU step of the same slab.
+    python tools/ring_rehearsal.py [--out profiles/r02/ring_rehearsal.json]"""
+import argparse, json, os, socket, sys
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import swmhd_amd as S
+from swmhd_amd import configs
+
+
+def timeit(fn, n, spin=60):
+    for _ in range(spin): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--out", default=None); ap.add_argument("--only", type=int, default=0); a = ap.parse_args()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = configs.config3_bickley()
+    y0, y1 = cfg["domain"]["y"]; yc, Ly = 0.5 * (y0 + y1), y1 - y0
+    res = {"device": torch.cuda.get_device_name(0), "workload": "config 3 fields on 4096 x Ny slabs, fp64, vector-invariant + Jacobian forcing"}
+    for Ny in ((a.only,) if a.only else (4096, 2048, 1024, 512)):
+        ydom = (yc - Ly * Ny / 4096 / 2, yc + Ly * Ny / 4096 / 2)
+        out = {}
+        for tag, ring in (("plain", False), ("ring_of_one", True)):
+            dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
+            g = dec.local_grid(S.RectilinearGrid, 4096, x=cfg["domain"]["x"], y=ydom)
+            m = S.ShallowWaterModel(g, formulation="VectorInvariant", decomp=dec)
+            m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
+            dt = 0.2 * min(g.dx, g.dy) / 4.2
+            out[tag + "_ms"] = timeit(lambda: m.time_steps(1, dt), 40)
+            out[tag + "_native_ring"] = m._ring is not None
+            m.synchronize(); m.close(); del m
+            torch.cuda.empty_cache()
+        out["ring_over_plain"] = out["ring_of_one_ms"] / out["plain_ms"]
+        res[f"4096x{Ny}"] = out
+        print(f"4096x{Ny}", json.dumps(out), flush=True)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        json.dump(res, open(a.out, "w"), indent=1)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
