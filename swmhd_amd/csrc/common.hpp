@@ -95,6 +95,10 @@ struct Rk3Args {
 // the row it had prefetched one iteration ago (PF rows of prefetch were in effect none).  With a fixed pattern the exact wait
 // is stated once, at the end of the iteration: only operations OLDER than the row about to enter the windows must be back.
 typedef int sw_v2i __attribute__((ext_vector_type(2)));
+// packed fp32: two adjacent columns of a row in one 64-bit register pair (v_pk_* arithmetic); _u = as it lies in global memory,
+// where a pair is only dword-aligned (the interior starts Hx = 3 floats into a row)
+typedef float sw_f2 __attribute__((ext_vector_type(2)));
+typedef sw_f2 sw_f2_u __attribute__((aligned(4)));
 constexpr unsigned SW_OOB = 0xFFFFFFC0u;   // >= any parent's size in bytes (the launcher keeps parents below 4 GiB - 64 B)
 template <typename T> __device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(T *parent, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(parent, 0, (int)bytes, 0x00020000);

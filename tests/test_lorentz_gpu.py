@@ -81,6 +81,32 @@ def test_outputs_outside_interior_untouched_and_row_ranges(swmhd, oracle, form):
         assert np.all(q[mask] == sentinel), "kernel wrote outside the requested rows / into halos"
 
 
+@pytest.mark.parametrize("H", [2, 3])
+@pytest.mark.parametrize("Nx", [16, 250, 252, 254, 505, 1300])
+def test_fp32_jacobian_marching_operator_at_strip_boundaries(swmhd, oracle, H, Nx):
+    """The fp32 row-marching Jacobian operator (252 output columns per workgroup): widths around the strip boundaries, the minimal halo
+    the Jacobian form accepts, non-periodic random halos (so that a wrong halo column shows), a row sub-range, and nothing written
+    outside it."""
+    Ny = 23
+    A, h = Hh.random_case(Nx, Ny, H, H, 300 + Nx, np.float32, periodic=False)
+    g, f = _fields(swmhd, Nx, Ny, H, A, h)
+    want = _oracle(oracle, "jacobian", A, h, g)
+    I = g.interior
+    got = _run(swmhd, "jacobian", g, f, strict=False, kernel="march")
+    for w, q in zip(want, got):
+        assert np.abs(w[I] - q[I]).max() <= TOL[np.float32] * np.abs(w[I]).max()
+    sentinel = -777.25
+    out = (swmhd.Field(g, dtype=torch.float32), swmhd.Field(g, dtype=torch.float32))
+    for o in out:
+        o.data.fill_(sentinel)
+    part = _run(swmhd, "jacobian", g, f, out=out, strict=False, kernel="march", rows=(5, 17))
+    for q, full in zip(part, got):
+        assert np.array_equal(q[H + 5:H + 17, H:H + Nx], full[H + 5:H + 17, H:H + Nx])
+        mask = np.ones_like(q, dtype=bool)
+        mask[H + 5:H + 17, H:H + Nx] = False
+        assert np.all(q[mask] == sentinel), "kernel wrote outside the requested rows / into halos"
+
+
 @pytest.mark.parametrize("name", ["gaussian_128", "two_gaussians_64"])
 def test_golden_fixtures(swmhd, name):
     """Committed fixtures (restatement-generated, tests/golden/make_golden.py) -- no oracle call here."""
