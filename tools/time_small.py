@@ -8,9 +8,11 @@ import os
 for N in [int(x) for x in os.environ.get('SIZES', '64,128,512,1024').split(',')]:
     g = S.RectilinearGrid(size=(N, N), x=(-5, 5), y=(-5, 5))
     for mode in ("eager",) if os.environ.get("SIZES") else ("eager", "graph"):
-        m = S.ShallowWaterModel(g, formulation="VectorInvariant")
-        m.set(u=lambda X, Y: 5 * Y * np.exp(-(X**2 + Y**2)) * 0.01, v=lambda X, Y: -5 * X * np.exp(-(X**2 + Y**2)) * 0.01,
-              h=lambda X, Y: np.ones_like(X), A=configs.two_gaussians(0.1))
+        form = os.environ.get("FORM", "VectorInvariant")
+        m = S.ShallowWaterModel(g, formulation=form)
+        n1, n2 = m.names[:2]
+        m.set(**{n1: lambda X, Y: 5 * Y * np.exp(-(X**2 + Y**2)) * 0.01, n2: lambda X, Y: -5 * X * np.exp(-(X**2 + Y**2)) * 0.01,
+              "h": lambda X, Y: np.ones_like(X), "A": configs.two_gaussians(0.1)})
         dt = 0.01 * 64 / N
         m.time_step(dt)
         if mode == "graph": m.capture_graph(dt)
@@ -18,4 +20,4 @@ for N in [int(x) for x in os.environ.get('SIZES', '64,128,512,1024').split(',')]
         t0 = time.perf_counter(); n = 1000
         m.time_steps(n, dt); torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        print(f"N={N:5d} {mode:5s}: {el/n*1e6:8.1f} us/step  {N*N*n/el/1e6:9.1f} Mcell-steps/s   finite={bool(torch.isfinite(m.solution['h'].data).all())}")
+        print(f"{form[:4]} N={N:5d} {mode:5s}: {el/n*1e6:8.1f} us/step  {N*N*n/el/1e6:9.1f} Mcell-steps/s   finite={bool(torch.isfinite(m.solution['h'].data).all())}")
