@@ -256,7 +256,7 @@ def main():
     if dist: dist.barrier()
     torch.cuda.synchronize()
     m.tendency_events = []
-    if m._ring is not None:
+    if m._ring is not None and not os.environ.get("SWMHD_BENCH_NO_LAUNCH_TIMING"):
         m.ring_time_launches(3 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -39,6 +39,16 @@ def main():
             m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
             dt = 0.2 * min(g.dx, g.dy) / 4.2
             out[tag + "_ms"] = timeit(lambda: m.time_steps(1, dt), 40)
+            # host side: wall time to ENQUEUE 40 steps (no synchronisation inside), one C call per step and one call for all 40
+            import time
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(40): m.time_steps(1, dt)
+            out[tag + "_enqueue_ms_per_step"] = (time.perf_counter() - t0) / 40 * 1e3
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            m.time_steps(40, dt)
+            out[tag + "_enqueue_ms_per_step_one_call"] = (time.perf_counter() - t0) / 40 * 1e3
+            torch.cuda.synchronize()
+            out[tag + "_ms_one_call"] = timeit(lambda: m.time_steps(40, dt), 3, spin=2) / 40
             out[tag + "_native_ring"] = m._ring is not None
             m.synchronize(); m.close(); del m
             torch.cuda.empty_cache()
