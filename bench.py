@@ -255,7 +255,7 @@ def main():
     m.synchronize()
     if dist: dist.barrier()
     torch.cuda.synchronize()
-    m.tendency_events = []
+    m.tendency_events = None if os.environ.get("SWMHD_BENCH_NO_LAUNCH_TIMING") else []   # (A/B knob: what the per-launch events cost)
     if m._ring is not None and not os.environ.get("SWMHD_BENCH_NO_LAUNCH_TIMING"):
         m.ring_time_launches(3 * args.steps)
     t0 = time.perf_counter()
@@ -292,7 +292,10 @@ def main():
                                         if dec.ring else "single GPU",
                        "dt": dt, "finite": finite, "kernel_source_hash": _lib.source_hash()},
         }
-        launches = [(a.elapsed_time(b), r) for a, b, r in m.tendency_events]
+        default_workload = (args.config == 3 and world == 1 and not args.strict and not dec.ring and args.n is None
+                            and args.formulation is None and bpe == 8)
+        ks, ksrc = None, None
+        launches = [(a.elapsed_time(b), r) for a, b, r in (m.tendency_events or [])]
         if m._ring is not None:
             launches = m.ring_launch_times()
         if launches:
@@ -319,8 +322,6 @@ def main():
             # HBM traffic from the PMC counters cannot be collected inside this process: the per-launch figure measured with
             # rocprofv3 --pmc on this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950
             # note of the microarchitecture guide) lives under profiles/ and is echoed ONLY while the kernel sources are unchanged.
-            default_workload = (args.config == 3 and world == 1 and not args.strict and not dec.ring and args.n is None
-                                and args.formulation is None and bpe == 8)
             tr, tsrc = committed("tendency_pmc_traffic.json")
             roof["traffic"] = tr.get("hbm_bytes_per_launch_corrected") if (tr and default_workload) else None
             roof["traffic_source"] = tsrc if default_workload else {"status": "not collected for this workload"}

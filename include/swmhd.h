@@ -71,6 +71,15 @@ int swmhd_version(void);
 /* Human-readable text for a return code of any entry point (static storage). */
 const char *swmhd_strerror(int rc);
 
+/* Timing events for benchmarks (no counterpart in the reference: its timings are wall-clock, SWMHD_example.jl:87-92).  HIP events
+ * created with hipEventDisableSystemFence: a default event performs a system-scope fence when it is recorded, which costs 1-1.5 %
+ * of a 4096^2 RK3 step with one pair per stage launch and 16 % when another stream's kernels run beside the timed launch.
+ * swmhd_event_elapsed_ms waits for `stop`. */
+int swmhd_event_create(void **event);
+int swmhd_event_record(void *event, void *stream);
+int swmhd_event_elapsed_ms(void *start, void *stop, float *ms);
+int swmhd_event_destroy(void *event);
+
 /* ------------------------------------------------------------------------------------------------
  * Jacobian-form Lorentz force.   Replaces lorentz_force_func_x / lorentz_force_func_y
  * (jacobian_formulation/sw_mhd_jacobian_functions.jl:20-26, built on Bx/By :1-7 and jacobian_x/y :10-18):

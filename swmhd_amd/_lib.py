@@ -36,6 +36,12 @@ def _declare(lib):
     lib.swmhd_version.restype = i
     lib.swmhd_strerror.restype = C.c_char_p
     lib.swmhd_strerror.argtypes = [i]
+    lib.swmhd_event_create.argtypes = [C.POINTER(p)]
+    lib.swmhd_event_record.argtypes = [p, p]
+    lib.swmhd_event_elapsed_ms.argtypes = [p, p, C.POINTER(C.c_float)]
+    lib.swmhd_event_destroy.argtypes = [p]
+    for n in ("create", "record", "elapsed_ms", "destroy"):
+        getattr(lib, "swmhd_event_" + n).restype = i
     for sfx, ft in (("f64", C.c_double), ("f32", C.c_float)):
         for form in ("jacobian", "divergence"):
             f = getattr(lib, f"swmhd_lorentz_{form}_{sfx}")
@@ -100,7 +106,7 @@ def _declare(lib):
 
 
 # every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
-EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] + [
+EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] + ["swmhd_event_" + n for n in ("create", "record", "elapsed_ms", "destroy")] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
         "fill_halo", "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
@@ -108,6 +114,33 @@ EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] 
     "swmhd_ring_" + name for name in ("available", "unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
                                       "launch_times")]
 RING_ID_BYTES = 128
+
+
+class TimingEvent:
+    """A HIP timing event without the system-scope fence (swmhd_event_*), with the two methods of torch.cuda.Event that the
+    benchmarks use.  `record` takes the raw stream handle (default: torch's current stream)."""
+
+    def __init__(self):
+        self._e = C.c_void_p()
+        check(lib().swmhd_event_create(C.byref(self._e)), "swmhd_event_create")
+
+    def record(self, stream=None):
+        if stream is None:
+            import torch
+            stream = torch.cuda.current_stream().cuda_stream
+        check(lib().swmhd_event_record(self._e, C.c_void_p(stream)), "swmhd_event_record")
+
+    def elapsed_time(self, stop):
+        ms = C.c_float()
+        check(lib().swmhd_event_elapsed_ms(self._e, stop._e, C.byref(ms)), "swmhd_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self._e:
+                lib().swmhd_event_destroy(self._e)
+        except Exception:
+            pass
 
 
 def lib():

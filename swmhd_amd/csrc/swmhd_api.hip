@@ -242,6 +242,25 @@ const char *swmhd_strerror(int rc) {
     }
 }
 
+int swmhd_event_create(void **event) {
+    if (!event) return SWMHD_EINVAL;
+    hipEvent_t e;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
+    if (rc != hipSuccess) return hiprc(rc);
+    *event = (void *)e;
+    return SWMHD_OK;
+}
+int swmhd_event_record(void *event, void *stream) {
+    return event ? hiprc(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)) : SWMHD_EINVAL;
+}
+int swmhd_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!start || !stop || !ms) return SWMHD_EINVAL;
+    const hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+    if (rc != hipSuccess) return hiprc(rc);
+    return hiprc(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+}
+int swmhd_event_destroy(void *event) { return event ? hiprc(hipEventDestroy((hipEvent_t)event)) : SWMHD_OK; }
+
 int swmhd_tendency_launch_geometry(int Nx, int rows, int formulation, int elem_size, int flags, int out[8]) {
     if (!out || Nx <= 0 || rows <= 0 || (elem_size != 4 && elem_size != 8)) return SWMHD_EINVAL;
     if (formulation != SWMHD_CONSERVATIVE && formulation != SWMHD_VECTOR_INVARIANT) return SWMHD_EINVAL;

@@ -222,7 +222,7 @@ class ShallowWaterModel:
     # --- calculate_tendencies! ------------------------------------------------------------------------------
     def calculate_tendencies(self, rows=None, stream=None):
         if self.tendency_events is not None and rows is None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = _lib.TimingEvent(), _lib.TimingEvent()
             e0.record()
             self._calculate_tendencies(rows, stream)
             e1.record()
@@ -262,7 +262,7 @@ class ShallowWaterModel:
         f = getattr(self._L, f"swmhd_tendencies_rk3_{self.sfx}")
         timed = self.tendency_events is not None and 2 * (j1 - j0) > g.Ny    # whole grid, or the interior launch of a slab
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = _lib.TimingEvent(), _lib.TimingEvent()
             e0.record()
         rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self._raw_fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
                self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,

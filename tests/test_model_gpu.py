@@ -501,3 +501,19 @@ def test_packed_fp32_marching_kernel(swmhd, oracle, lor, shape):
     for a, b in zip(ms[0].fields, ms[1].fields):
         assert (a.data[I] - b.data[I]).abs().max().item() <= 2e-5 * max(b.data[I].abs().max().item(), 1.0)
         assert torch.isfinite(a.data).all()
+
+
+def test_timing_events_without_system_fence(swmhd):
+    """swmhd_event_*: the timing events bench.py brackets every stage launch with (hipEventDisableSystemFence)."""
+    g = swmhd.RectilinearGrid(size=(512, 512), x=(-5, 5), y=(-5, 5))
+    m = swmhd.ShallowWaterModel(g, formulation="VectorInvariant")
+    m.set(u=lambda X, Y: 0.01 * Y, v=lambda X, Y: 0 * X, h=lambda X, Y: 1 + 0 * X, A=lambda X, Y: np.exp(-(X ** 2 + Y ** 2)))
+    m.tendency_events = []
+    m.time_step(1e-3)
+    m.synchronize()
+    assert len(m.tendency_events) == 3
+    for a, b, rows in m.tendency_events:
+        assert rows == 512 and 0.0 < a.elapsed_time(b) < 50.0      # ms
+    e0, e1 = swmhd._lib.TimingEvent(), swmhd._lib.TimingEvent()
+    e0.record(); e1.record()
+    assert 0.0 <= e0.elapsed_time(e1) < 10.0
