@@ -10,7 +10,10 @@ h/u, fp64), synthetic initial condition resident in HBM before timing.
   --config 3|4|5   3: 4096^2 Jacobian (default); 4: 8192^2 divergence formulation; 5: 16384^2 Jacobian (2048 rows per GPU)
   --scaling weak|strong   N > 1: weak = every rank owns a full per-GPU slab (config 3: 4096 x 4096 per GPU, config 5: 16384 x 2048
                    per GPU, config 4: 8192 x 1024 per GPU); strong = the fixed global grid cut into N y-slabs (config 3: 4096 x 4096/N,
-                   config 4: 8192 x 8192/N).  Defaults: weak for configs 3 and 5, strong for config 4 (as BASELINE.json words them).
+                   config 4: 8192 x 8192/N).  Defaults as BASELINE.json words them: strong for config 3 ("4096^2 periodic grid at 1/2/4/8")
+                   and config 4 ("8192 x 8192 ... 8 x MI355X"), weak for config 5 ("weak-scaled across 8").  When --scaling is not given
+                   and N > 1, the OTHER scaling is measured too, after the headline, same K and W, and reported in the same line as
+                   "companion" (--no-companion skips it): one driver run yields both curves.
   N > 1 without a launcher (RANK unset): bench.py starts N worker processes itself (one per GPU) and forwards rank 0's line.
 
 Halo rows move by RCCL send/recv between ring neighbours (native swmhd_ring driver), overlapped with the interior rows on a second
@@ -34,7 +37,7 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 VALU_NS_PER_WAVE_INST = 2.05   # one fp64 wave-instruction per 2.05 ns per SIMD (tools/valu_probe.hip: 4 cycles at ~1.95 GHz under load)
 
 CONFIGS = {
-    3: dict(builder="config3_bickley", Nx=4096, Ny=4096, slab=4096, form="VectorInvariant", default_scaling="weak",
+    3: dict(builder="config3_bickley", Nx=4096, Ny=4096, slab=4096, form="VectorInvariant", default_scaling="strong",
             text="Bickley-jet h/u + current-sheet A (BASELINE config 3)"),
     4: dict(builder="config4_two_gaussians", Nx=8192, Ny=8192, slab=1024, form="Conservative", default_scaling="strong",
             text="two-Gaussian A, h = 1, uh = vh = 0 (BASELINE config 4)"),
@@ -60,6 +63,7 @@ def parse(argv=None):
     p.add_argument("--torch-ring", action="store_true", help="multi-GPU: exchange through torch.distributed p2p instead of the native ring")
     p.add_argument("--force-ring", action="store_true",
                    help="N=1 rehearsal of the multi-GPU step: y halos through the RCCL ring exchange (sends to self) + overlap")
+    p.add_argument("--no-companion", action="store_true", help="N > 1: do not also measure the other scaling mode")
     p.add_argument("--rendezvous-only", action="store_true",
                    help="create the process group, barrier, print {'launcher': 'ok', ...} and exit (tests the launcher without a GPU)")
     return p.parse_args(argv)
@@ -143,6 +147,42 @@ def workload(args, world):
     if Ny_global % world:
         raise SystemExit(f"bench.py: Ny={Ny_global} is not divisible by --gpus {world}")
     return cfg, Nx, Ny_global, Ny_global // world, form, scaling, ydom
+
+
+def companion_run(args, world, rank, dist, scaling):
+    """The same K timed steps (after 40 + W untimed ones) on the workload of the OTHER scaling mode; all ranks take part.  Returns
+    the entries of the "companion" object (rank 0 prints them)."""
+    import copy
+    import torch
+    import swmhd_amd as S
+    a2 = copy.copy(args); a2.scaling = scaling
+    cfg, Nx, Ny_global, Ny_local, form, _, ydom = workload(a2, world)
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    dec = S.SlabDecomposition(Ny_global, world, rank, force_ring=args.force_ring)
+    g = dec.local_grid(S.RectilinearGrid, Nx, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
+    dt = args.dt if args.dt is not None else 0.2 * min(g.dx, g.dy) / 4.2
+    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=args.strict, decomp=dec, native_ring=not args.torch_ring, dtype=dtype)
+    n1, n2 = m.names[:2]
+    m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
+    for _ in range(40 + args.warmup):
+        m.time_step(dt)
+    m.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.time_step(dt)
+    m.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = t.item()
+    finite = all(torch.isfinite(f.data).all().item() for f in m.fields)
+    m.close()
+    return {"scaling": scaling, "value": Nx * Ny_global * args.steps / wall / 1e6, "unit": "Mcell-steps/s", "ms_per_step": wall / args.steps * 1e3,
+            "steps": args.steps, "warmup": args.warmup, "workload": f"global grid {Nx}x{Ny_global} ({Nx}x{Ny_local} cells per GPU)",
+            "finite": finite, "timing": "as the headline: barrier + synchronize on both sides, max over ranks"}
 
 
 def committed(name):
@@ -242,7 +282,7 @@ def main():
     cfg, Nx, Ny_global, Ny_local, form, scaling, ydom = workload(args, world)
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     dec = S.SlabDecomposition(Ny_global, world, rank, force_ring=args.force_ring)
-    g = dec.local_grid(S.RectilinearGrid, Nx, x=cfg["domain"]["x"], y=ydom)
+    g = dec.local_grid(S.RectilinearGrid, Nx, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
     dt = args.dt if args.dt is not None else 0.2 * min(g.dx, g.dy) / 4.2      # CFL 0.2 on sqrt(g h) + U ~ 4.2
     m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=args.strict, decomp=dec, native_ring=not args.torch_ring, dtype=dtype)
     n1, n2 = m.names[:2]
@@ -270,6 +310,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
     finite = all(torch.isfinite(f.data).all().item() for f in m.fields)
+    companion = None
+    if (world > 1 or args.force_ring) and args.scaling is None and args.n is None and not args.no_companion:
+        # (--force-ring: one rank, both workloads coincide -- it only rehearses this code path on a one-GPU box)
+        try:
+            companion = companion_run(args, world, rank, dist, "weak" if scaling == "strong" else "strong")
+        except Exception as exc:   # the headline line must survive a failure here (an error every rank hits alike)
+            companion = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         cells_global = Nx * Ny_global
@@ -292,6 +339,8 @@ def main():
                                         if dec.ring else "single GPU",
                        "dt": dt, "finite": finite, "kernel_source_hash": _lib.source_hash()},
         }
+        if companion is not None:
+            line["companion"] = companion
         default_workload = (args.config == 3 and world == 1 and not args.strict and not dec.ring and args.n is None
                             and args.formulation is None and bpe == 8)
         ks, ksrc = None, None

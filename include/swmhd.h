@@ -173,7 +173,10 @@ int swmhd_fill_halo_f32(float *const *fields, int nf, int Nx, int Ny, int Hx, in
  *       model configuration of divergence_formulation/divergence_sw_mhd.jl:19-31
  * The base right-hand side is Oceananigans' (third-party, un-vendored by the reference): it is restated from
  * the library's published scheme, parity UNPINNED; the forcing is the reference's own.
- * All fields need halo >= 3, filled (swmhd_fill_halo for Bounded directions).  Rows j_begin+1..j_end are computed.
+ * All fields need halo >= 3, filled (swmhd_fill_halo for Bounded directions).  Rows j_begin+1..j_end are computed; with a deeper
+ * y halo (Hy > 3, y neither wrapped nor Bounded) the range may reach Hy - 3 rows beyond the interior on either side
+ * (-(Hy-3) <= j_begin, j_end <= Ny + Hy - 3): those halo rows then receive the tendency / new state their periodic image or
+ * neighbouring slab gets -- the slab driver's deep-halo schedule (swmhd_ring_step_rk3) exchanges once per step that way.
  * flags SWMHD_BOUNDED_X / SWMHD_BOUNDED_Y: that direction is Bounded -- within the boundary buffers WENO5 drops to third- and
  * first-order upwind and the centred fourth-order advecting velocity to second order (Oceananigans' topologically conditional
  * interpolation, restated; parity UNPINNED), the divergence forcing takes the reference's wall branches, and the tendency of the
@@ -303,7 +306,13 @@ int swmhd_ring_exchange_y_f32(swmhd_ring *ring, float *const *fields, int nfield
  *   exit : the y exchange of the final state is IN FLIGHT on the comm stream: call swmhd_ring_join(ring, stream) before
  *          anything but swmhd_ring_step_rk3 reads the y halos (or reuses the buffers) on `stream`
  * flags must not carry SWMHD_WRAP_Y (y images belong to the neighbours); with SWMHD_WRAP_X no x-halo kernel runs between a stage and
- * its exchange and the x halos of the returned state are stale.  Ny >= 2*Hy+1.  Other arguments and state_in_alt as swmhd_step_rk3. */
+ * its exchange and the x halos of the returned state are stale.  Ny >= 2*Hy+1.  Other arguments and state_in_alt as swmhd_step_rk3.
+ * Deep-halo schedule (taken when Hy >= 9, Ny >= 32 and SWMHD_WRAP_X is set): ONE exchange of Hy rows per step instead of one of 3
+ * rows per stage.  The slab evaluates the rows of its neighbours that stages 2 and 3 need inside its own halo (18 redundant rows
+ * per step): stage k computes interior rows [3,9,12][k] .. Ny - [3,9,12][k] on `stream` and the boundary zones
+ * [-6,-3,0][k] .. [3,9,12][k] (and the mirror image at the top) on the comm stream behind the exchange.  `stream` waits for the comm
+ * stream once per step instead of once per stage, and a thin slab is bound by its interior launches rather than by the chain
+ * exchange -> strips -> exchange.  Entry / exit conditions are the same with "y halos" meaning all Hy rows. */
 int swmhd_ring_step_rk3_f64(swmhd_ring *ring, double *const *q, double *const *q_alt, double *const *Ga, double *const *Gb,
                             int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
                             double g, double f, int formulation, int lorentz, double dt, int nsteps,

@@ -131,6 +131,9 @@ struct ProgressPriority {
         if (it == t3) __builtin_amdgcn_s_setprio(0);
     }
 };
+// (Slab driver, two streams on one chip: starting the interior launch one priority level lower and holding the boundary-zone launch
+//  beside it at the top level was measured and dropped -- the ring-of-one step got 2-8 % SLOWER at every slab height: the falling
+//  priorities are what keeps the interior's own workgroups in step.)
 
 // ---- launch geometry of the row-marching kernels --------------------------------------------------------------------------
 // One workgroup = a strip of nt - 2*xh output columns x LY rows; the grid is a whole number of rounds of resident workgroups.

@@ -166,6 +166,68 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
         if (state_in_alt) *state_in_alt = swaps & 1;
         return code;
     };
+    if ((flags & SWMHD_WRAP_X) && Hy >= 9 && Ny >= 32) {
+        // ---- deep-halo schedule: ONE exchange per step instead of one per stage ------------------------------------------------
+        // With Hy >= 9 a slab evaluates the rows of its neighbours it needs for stages 2 and 3 itself (redundantly: 18 extra rows
+        // per step) from the 9 halo rows exchanged once per step.  Rows per stage (north side mirrored):
+        //     stage 1   interior [3, Ny-3)     boundary [-6, 3)      stage 2   interior [9, Ny-9)    boundary [-3, 9)
+        //     stage 3   interior [12, Ny-12)   boundary [0, 12)
+        // Interior launches (main stream) read only what earlier interior launches of the same step wrote -- plus, for stage 1,
+        // the boundary rows of the previous step's last stage: ONE wait of the main stream per step.  Boundary launches (comm
+        // stream, behind the exchange) read rows of the previous interior launch: the comm stream waits twice, off the critical
+        // path.  Stage 2's interior starts at row 9, not 6, because it overwrites the buffer whose rows [0, 9) the exchange in
+        // flight is still sending.  A thin slab (strong scaling) is then bound by its interior launches, not by the chain
+        // exchange -> strips -> exchange of the per-stage schedule below (tools/ring_rehearsal.py).
+        const int ilo[3] = {3, 9, 12}, blo[3] = {-6, -3, 0};
+        // boundary zones of a wide slab take the row-marching kernel too (both zones in one launch, a few dozen workgroups beside the
+        // interior launch); the LDS-tiled kernel re-loads a 10-row halo per 4-row tile and costs ten times as much per row
+        const int bflags = flags | ((!(flags & (SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL)) && Nx >= 1024) ? SWMHD_MARCH_KERNEL : 0);
+        for (int n = 0; n < nsteps; ++n) {
+            for (int st = 0; st < 3; ++st) {
+                const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
+                const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+                const T *const *pgm = st == 0 ? nullptr : cgm;
+                const int store = st < 2 ? 1 : 0;
+                const int jb = ilo[st], je = Ny - ilo[st];
+                const bool timed = r->t0.size() < r->tcap;
+                hipEvent_t a = nullptr, b = nullptr;
+                if (timed) {
+                    if ((e = hipEventCreateWithFlags(&a, hipEventDisableSystemFence)) != hipSuccess) return bail(hipfail(r, "hipEventCreate", e));
+                    if ((e = hipEventCreateWithFlags(&b, hipEventDisableSystemFence)) != hipSuccess) { (void)hipEventDestroy(a); return bail(hipfail(r, "hipEventCreate", e)); }
+                    (void)hipEventRecord(a, s);
+                }
+                int rc = Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st], zet[st],
+                                       store, jb, je, flags | SWMHD_LEAVE_ROOM, (void *)s);
+                if (timed) {
+                    if (rc) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
+                    else { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
+                }
+                if (rc) return bail(rc);
+                if (st < 2) {   // the next boundary launch reads rows of this interior launch
+                    if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return bail(hipfail(r, "record", e));
+                }
+                // boundary rows of this stage, both sides in one launch, behind the exchange (stage 1) / the previous boundary launch
+                if ((rc = swmhd::tendencies_rk3_two_ranges<T>(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, (long)sy, dx, dy, grav, fcor, formulation,
+                                                              lorentz, dt, gam[st], zet[st], store, blo[st], ilo[st], Ny - ilo[st],
+                                                              Ny - blo[st], bflags, (void *)c)))
+                    return bail(rc);
+                if (st < 2) {
+                    if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
+                }
+                for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
+                ++swaps;
+            }
+            // end of the step: the main stream's next interior launch reads the last boundary rows; the exchange of the new state
+            // (its 9 edge rows are exactly those boundary rows) follows them on the comm stream
+            r->pending = nullptr;
+            if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return bail(hipfail(r, "record", e));
+            if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
+            if (int rc = exchange<T>(r, cur, 4, Nx, Ny, Hx, Hy, sy, c)) return bail(rc);
+            r->pending = cur[0];
+        }
+        if (state_in_alt) *state_in_alt = swaps & 1;
+        return SWMHD_OK;
+    }
     for (int n = 0; n < nsteps; ++n)
         for (int st = 0; st < 3; ++st) {
             const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};

@@ -97,8 +97,11 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     if (!q1 || !q2 || !h || !A || !G1 || !G2 || !Gh || !GA) return SWMHD_EINVAL;
     if (Nx <= 0 || Ny <= 0 || Hx < 0 || Hy < 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     if (!(dx > T(0)) || !(dy > T(0))) return SWMHD_EINVAL;
-    if (j0 < 0 || j1 > Ny || j0 > j1) return SWMHD_EINVAL;
-    if (j1b > j0b && (j0b < j1 || j1b > Ny)) return SWMHD_EINVAL;   // (internal: second row range of the slab driver, above the first)
+    // Rows may reach up to Hy - 3 rows into the y halo (the stencil stays inside the padded array) unless y is wrapped or Bounded:
+    // a slab with a deep halo evaluates its neighbours' edge rows itself instead of exchanging them every stage (ring.hip).
+    const int ext = ((flags & (SWMHD_WRAP_Y | SWMHD_BOUNDED_Y)) || Hy < 3) ? 0 : Hy - 3;
+    if (j0 < -ext || j1 > Ny + ext || j0 > j1) return SWMHD_EINVAL;
+    if (j1b > j0b && (j0b < j1 || j1b > Ny + ext)) return SWMHD_EINVAL;   // (internal: second row range of the slab driver, above the first)
     if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_EINVAL;
     if (((flags & SWMHD_BOUNDED_X) && (flags & SWMHD_WRAP_X)) || ((flags & SWMHD_BOUNDED_Y) && (flags & SWMHD_WRAP_Y))) return SWMHD_EINVAL;
     if ((flags & (SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) && (flags & SWMHD_MARCH_KERNEL)) return SWMHD_ENOTSUP;   // walls: LDS-tiled kernel only

@@ -28,6 +28,11 @@ class SlabDecomposition:
         # path on with ONE rank (every send goes to self): the RCCL rehearsal a one-GPU box allows (tools/ring_selftest.py).
         self.ring = world_size > 1 or force_ring
 
+    def ring_halo(self):
+        """Halo for the slab's grid: 9 rows in y where the native ring driver can use them (swmhd_ring_step_rk3's deep-halo schedule:
+        one neighbour exchange per RK3 step instead of one per stage; needs Hy >= 9 and a slab of >= 32 rows), else the stencil's 3."""
+        return (3, 9) if (self.ring and self.Ny_local >= 32) else (3, 3)
+
     def local_grid(self, grid_cls, Nx, x, y, halo=(3, 3), topology=("Periodic", "Periodic", "Flat")):
         return grid_cls(size=(Nx, self.Ny_local), x=x, y=y, halo=halo, topology=topology,
                         j_offset=self.j_offset, Ny_global=self.Ny_global)

@@ -41,7 +41,7 @@ def test_world_size_mismatch_is_an_error_not_an_assert():
 
 
 @pytest.mark.parametrize("config,scaling,world,want", [
-    (3, None, 1, (4096, 4096, 4096, "weak")), (3, None, 8, (4096, 32768, 4096, "weak")), (3, "strong", 8, (4096, 4096, 512, "strong")),
+    (3, None, 1, (4096, 4096, 4096, "strong")), (3, None, 8, (4096, 4096, 512, "strong")), (3, "weak", 8, (4096, 32768, 4096, "weak")),
     (4, None, 8, (8192, 8192, 1024, "strong")), (4, None, 1, (8192, 8192, 8192, "strong")), (4, "weak", 2, (8192, 2048, 1024, "weak")),
     (5, None, 1, (16384, 2048, 2048, "weak")), (5, None, 8, (16384, 16384, 2048, "weak")),
 ])

@@ -517,3 +517,57 @@ def test_timing_events_without_system_fence(swmhd):
     e0, e1 = swmhd._lib.TimingEvent(), swmhd._lib.TimingEvent()
     e0.record(); e1.record()
     assert 0.0 <= e0.elapsed_time(e1) < 10.0
+
+
+@pytest.mark.parametrize("form", ["VectorInvariant", "Conservative"])
+@pytest.mark.parametrize("kernel", ["strict", "tile", "march"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_rows_reaching_into_a_deep_halo(swmhd, form, kernel, dtype):
+    """swmhd_tendencies_rk3 with Hy = 9: the row range may reach 6 rows into the y halo; those rows get what their periodic images
+    get.  Compared with the same call over the interior only: extended rows == the periodic images of interior rows (bitwise: the
+    same kernel and arithmetic), rows further out untouched, and out-of-range requests are refused."""
+    import ctypes
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    L = swmhd._lib
+    Nx, Ny, H = (600, 80, 9) if kernel == "march" else (130, 40, 9)
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, Lx), y=(0, Ly), halo=(3, H))
+    m = swmhd.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=(kernel == "strict"), dtype=dtype)
+    if form == "VectorInvariant":
+        m.set(u=uf, v=vf, h=hf, A=Af)
+    else:
+        m.set(uh=lambda X, Y: hf(X, Y) * uf(X, Y), vh=lambda X, Y: hf(X, Y) * vf(X, Y), h=hf, A=Af)
+    q = [f for f in m.fields]                      # halos current (x and y, depth 9)
+    sfx = "f64" if dtype == torch.float64 else "f32"
+    fn = getattr(L.lib(), f"swmhd_tendencies_rk3_{sfx}")
+    flags = {"strict": L.STRICT, "tile": L.TILE_KERNEL, "march": L.MARCH_KERNEL}[kernel]
+    sentinel = -777.25
+
+    def run(j0, j1, fl=flags):
+        new = [swmhd.Field(g, dtype=dtype) for _ in range(4)]
+        G = [swmhd.Field(g, dtype=dtype) for _ in range(4)]
+        for f in new + G:
+            f.data.fill_(sentinel)
+        rc = fn(L.ptr_array([f.ptr for f in q]), L.ptr_array([f.ptr for f in new]), L.ptr_array([f.ptr for f in G]), None,
+                Nx, Ny, 3, H, q[0].stride_y, g.dx, g.dy, 9.81, 1.0, m.form_code, m.lorentz_code, 1e-3, 8.0 / 15.0, 0.0, 1, j0, j1,
+                fl, None)
+        torch.cuda.synchronize()
+        return rc, [f.numpy() for f in new], [f.numpy() for f in G]
+
+    rc, new_i, G_i = run(0, Ny)
+    assert rc == 0
+    rc, new_e, G_e = run(-6, Ny + 6)
+    assert rc == 0
+    # (the fast marching kernel carries y-fluxes from row to row and forms them directly in a segment's prologue: which of the two
+    #  a row gets depends on where the segments start, so there the comparison is to rounding, not bitwise)
+    tol = 0.0 if kernel != "march" else (1e-12 if dtype == torch.float64 else 2e-5)
+    same = lambda a, b: np.array_equal(a, b) if tol == 0.0 else np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1.0)
+    for full, ext in zip(new_i + G_i, new_e + G_e):
+        I = (slice(H, H + Ny), slice(3, 3 + Nx))
+        assert same(full[I], ext[I])
+        assert same(ext[H - 6:H, 3:3 + Nx], full[H + Ny - 6:H + Ny, 3:3 + Nx])      # south halo rows = images of the top rows
+        assert same(ext[H + Ny:H + Ny + 6, 3:3 + Nx], full[H:H + 6, 3:3 + Nx])
+        assert np.all(ext[:H - 6] == sentinel) and np.all(ext[H + Ny + 6:] == sentinel)
+        assert np.all(ext[:, :3] == sentinel) and np.all(ext[:, 3 + Nx:] == sentinel)
+    EINVAL = 1
+    assert run(-7, Ny)[0] == EINVAL and run(0, Ny + 7)[0] == EINVAL
+    assert run(-1, Ny, flags | L.WRAP_Y)[0] == EINVAL              # wrapped y: no rows outside the interior

@@ -73,6 +73,67 @@ def test_ring_of_one_is_the_periodic_model_bitwise(rccl_world_of_one, form, dtyp
     assert da == db
 
 
+def _interior(m):
+    m.synchronize()
+    return np.stack([f.numpy()[m.grid.interior] for f in m.fields])
+
+
+@pytest.mark.parametrize("form", ["VectorInvariant", "Conservative"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_deep_halo_schedule_is_the_periodic_model_bitwise(rccl_world_of_one, form, dtype):
+    """Slab grids with Hy = 9 (SlabDecomposition.ring_halo) take swmhd_ring_step_rk3's deep-halo schedule: one exchange per step,
+    boundary rows of stages 1-2 evaluated redundantly inside the halo.  Strict build: every row is the same arithmetic whoever
+    computes it, so the interiors equal the plain periodic model's bit for bit -- single steps (the exchange stays in flight
+    between calls), several steps per call, and after a join + diagnostics in between."""
+    import swmhd_amd as S
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    N = 96
+    ref = _model(S, form, N, True, ring=False, dtype=dtype)
+    dec = S.SlabDecomposition(N, 1, 0, force_ring=True)
+    assert dec.ring_halo() == (3, 9)
+    g = dec.local_grid(S.RectilinearGrid, N, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo())
+    rng = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=True, decomp=dec, dtype=dtype)
+    if form == "VectorInvariant":
+        rng.set(u=uf, v=vf, h=hf, A=Af)
+    else:
+        rng.set(uh=lambda X, Y: hf(X, Y) * uf(X, Y), vh=lambda X, Y: hf(X, Y) * vf(X, Y), h=hf, A=Af)
+    assert rng._ring is not None and g.Hy == 9
+    assert np.array_equal(_interior(ref), _interior(rng))
+    for _ in range(3):
+        ref.time_step(DT); rng.time_step(DT)
+    assert np.array_equal(_interior(ref), _interior(rng))
+    assert ref.diagnostics() == rng.diagnostics()
+    ref.time_steps(4, DT); rng.time_steps(4, DT)
+    a, b = _interior(ref), _interior(rng)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    ref.time_step(DT); rng.time_step(DT)
+    assert np.array_equal(_interior(ref), _interior(rng))
+    # the y halos of the returned state are the periodic images (the exchange of the final state has been joined by _interior)
+    for f in rng.fields:
+        p = f.numpy()
+        assert np.array_equal(p[:9, 3:-3], p[N:N + 9, 3:-3]) and np.array_equal(p[N + 9:, 3:-3], p[9:18, 3:-3])
+
+
+def test_deep_halo_fast_kernels_thin_and_tall_slabs(rccl_world_of_one):
+    """Fast build, deep-halo schedule: interior rows on the row-marching kernel, boundary rows on the LDS-tiled kernel; a thin
+    (4096 x 64: boundary zones almost meet) and a taller slab against the plain periodic model within the fast tolerance."""
+    import swmhd_amd as S
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    for Nx, Ny in ((4096, 64), (2048, 1024)):
+        out = []
+        for ring in (False, True):
+            dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
+            g = dec.local_grid(S.RectilinearGrid, Nx, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo())
+            m = S.ShallowWaterModel(g, 9.81, 1.0, formulation="VectorInvariant", decomp=dec)
+            m.set(u=uf, v=vf, h=hf, A=Af)
+            m.time_steps(2, 1e-4); m.time_step(1e-4)
+            out.append(_interior(m))
+        a, b = out
+        assert np.isfinite(a).all()
+        for k in range(4):
+            assert np.abs(a[k] - b[k]).max() <= 1e-12 * max(np.abs(a[k]).max(), 1.0), (Nx, Ny, k)
+
+
 def test_ring_fast_kernels_large_slab(rccl_world_of_one):
     """2048 x 1024 slab: interior rows take the row-marching kernel, the strips the tile kernel; fast build tolerance."""
     import swmhd_amd as S

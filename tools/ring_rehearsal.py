@@ -34,7 +34,7 @@ def main():
         out = {}
         for tag, ring in (("plain", False), ("ring_of_one", True)):
             dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
-            g = dec.local_grid(S.RectilinearGrid, 4096, x=cfg["domain"]["x"], y=ydom)
+            g = dec.local_grid(S.RectilinearGrid, 4096, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
             m = S.ShallowWaterModel(g, formulation="VectorInvariant", decomp=dec)
             m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
             dt = 0.2 * min(g.dx, g.dy) / 4.2
