@@ -114,24 +114,31 @@ def test_deep_halo_schedule_is_the_periodic_model_bitwise(rccl_world_of_one, for
         assert np.array_equal(p[:9, 3:-3], p[N:N + 9, 3:-3]) and np.array_equal(p[N + 9:, 3:-3], p[9:18, 3:-3])
 
 
-def test_deep_halo_fast_kernels_thin_and_tall_slabs(rccl_world_of_one):
-    """Fast build, deep-halo schedule: interior rows on the row-marching kernel, boundary rows on the LDS-tiled kernel; a thin
-    (4096 x 64: boundary zones almost meet) and a taller slab against the plain periodic model within the fast tolerance."""
+@pytest.mark.parametrize("form,dtype", [("VectorInvariant", torch.float64), ("Conservative", torch.float64), ("VectorInvariant", torch.float32)])
+def test_deep_halo_fast_kernels_thin_and_tall_slabs(rccl_world_of_one, form, dtype):
+    """Fast build, deep-halo schedule: interior rows AND (Nx >= 1024) both boundary zones per launch on the row-marching kernels --
+    vector-invariant, conservative and the packed fp32 kernel with their second row range; a thin slab (4096 x 64: the boundary zones
+    almost meet) and a taller one against the plain periodic model within the fast tolerance."""
     import swmhd_amd as S
     from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
     for Nx, Ny in ((4096, 64), (2048, 1024)):
         out = []
         for ring in (False, True):
             dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
             g = dec.local_grid(S.RectilinearGrid, Nx, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo())
-            m = S.ShallowWaterModel(g, 9.81, 1.0, formulation="VectorInvariant", decomp=dec)
-            m.set(u=uf, v=vf, h=hf, A=Af)
+            m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, decomp=dec, dtype=dtype)
+            if form == "VectorInvariant":
+                m.set(u=uf, v=vf, h=hf, A=Af)
+            else:
+                m.set(uh=lambda X, Y: hf(X, Y) * uf(X, Y), vh=lambda X, Y: hf(X, Y) * vf(X, Y), h=hf, A=Af)
             m.time_steps(2, 1e-4); m.time_step(1e-4)
             out.append(_interior(m))
+            m.close()
         a, b = out
         assert np.isfinite(a).all()
         for k in range(4):
-            assert np.abs(a[k] - b[k]).max() <= 1e-12 * max(np.abs(a[k]).max(), 1.0), (Nx, Ny, k)
+            assert np.abs(a[k] - b[k]).max() <= tol * max(np.abs(a[k]).max(), 1.0), (Nx, Ny, k)
 
 
 def test_ring_fast_kernels_large_slab(rccl_world_of_one):
