@@ -165,7 +165,9 @@ ring_join(ring) = check(ccall((:swmhd_ring_join, libswmhd), Cint, (Ptr{Cvoid}, P
     ring_steps!(ring, q, q_alt, Ga, Gb, grid, Δt, n; ...) -> state_in_alt::Bool
 
 `native_steps!` for one y-slab of the ring (`grid` is the LOCAL slab grid, halos of `q` filled on entry): the neighbour exchange of
-every stage runs on the ring's stream while the interior rows of the next stage compute.
+every stage runs on the ring's stream while the interior rows of the next stage compute.  Build the slab grid with `halo = (3, 9)`
+(and pass `flags = SWMHD_FAST | SWMHD_WRAP_X`) to get the deep-halo schedule: one exchange of 9 rows per RK3 step instead of 3 rows per stage, boundary
+rows of stages 1-2 evaluated redundantly inside the halo (include/swmhd.h, swmhd_ring_step_rk3).
 """
 function ring_steps!(ring, q, q_alt, Ga, Gb, grid, Δt, n; formulation = VECTOR_INVARIANT, lorentz = LORENTZ_JACOBIAN, g = 9.81, f = 1.0,
                      flags = SWMHD_FAST)
