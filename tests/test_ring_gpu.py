@@ -141,6 +141,41 @@ def test_deep_halo_fast_kernels_thin_and_tall_slabs(rccl_world_of_one, form, dty
             assert np.abs(a[k] - b[k]).max() <= tol * max(np.abs(a[k]).max(), 1.0), (Nx, Ny, k)
 
 
+def test_deep_halo_schedule_under_real_concurrency(rccl_world_of_one):
+    """Hazard check of the deep-halo schedule with launches long enough to overlap on the chip (the 96^2 case above is over before
+    the other stream starts): (a) strict kernels, 2048 x 40 and 2048 x 64 slabs, 60 steps in calls of 1 and 20 -- bitwise equal to the
+    periodic model; (b) fast kernels, 4096 x 512, two independent runs of 60 steps -- bitwise equal to each other (a race between
+    the interior launches, the boundary launches and the exchange would show as a difference)."""
+    import swmhd_amd as S
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+
+    def build(Nx, Ny, ring, strict):
+        dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
+        g = dec.local_grid(S.RectilinearGrid, Nx, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo())
+        m = S.ShallowWaterModel(g, 9.81, 1.0, formulation="VectorInvariant", strict=strict, decomp=dec)
+        m.set(u=uf, v=vf, h=hf, A=Af)
+        return m
+
+    for Ny in (40, 64):
+        ref, rng = build(2048, Ny, False, True), build(2048, Ny, True, True)
+        for m in (ref, rng):
+            for _ in range(20):
+                m.time_step(2e-5)
+            m.time_steps(20, 2e-5); m.time_steps(20, 2e-5)
+        a, b = _interior(ref), _interior(rng)
+        assert np.isfinite(a).all() and np.array_equal(a, b), Ny
+        rng.close()
+    runs = []
+    for _ in range(2):
+        m = build(4096, 512, True, False)
+        m.time_steps(30, 2e-5)
+        for _ in range(30):
+            m.time_step(2e-5)
+        runs.append(_interior(m))
+        m.close()
+    assert np.isfinite(runs[0]).all() and np.array_equal(runs[0], runs[1])
+
+
 def test_ring_fast_kernels_large_slab(rccl_world_of_one):
     """2048 x 1024 slab: interior rows take the row-marching kernel, the strips the tile kernel; fast build tolerance."""
     import swmhd_amd as S
