@@ -21,22 +21,24 @@ def timeit(fn, n, spin=60):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--out", default=None); ap.add_argument("--only", type=int, default=0); a = ap.parse_args()
+    ap = argparse.ArgumentParser(); ap.add_argument("--out", default=None); ap.add_argument("--only", type=int, default=0); ap.add_argument("--config", type=int, default=3, choices=[3, 4]); a = ap.parse_args()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    cfg = configs.config3_bickley()
+    cfg = configs.config3_bickley() if a.config == 3 else configs.config4_two_gaussians()
+    NX, FULL, form = (4096, 4096, "VectorInvariant") if a.config == 3 else (8192, 8192, "Conservative")
     y0, y1 = cfg["domain"]["y"]; yc, Ly = 0.5 * (y0 + y1), y1 - y0
-    res = {"device": torch.cuda.get_device_name(0), "workload": "config 3 fields on 4096 x Ny slabs, fp64, vector-invariant + Jacobian forcing"}
-    for Ny in ((a.only,) if a.only else (4096, 2048, 1024, 512)):
-        ydom = (yc - Ly * Ny / 4096 / 2, yc + Ly * Ny / 4096 / 2)
+    res = {"device": torch.cuda.get_device_name(0), "workload": f"config {a.config} fields on {NX} x Ny slabs, fp64, {form}"}
+    for Ny in ((a.only,) if a.only else ((4096, 2048, 1024, 512) if a.config == 3 else (4096, 2048, 1024))):
+        ydom = (yc - Ly * Ny / FULL / 2, yc + Ly * Ny / FULL / 2)
         out = {}
         for tag, ring in (("plain", False), ("ring_of_one", True)):
             dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
-            g = dec.local_grid(S.RectilinearGrid, 4096, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
-            m = S.ShallowWaterModel(g, formulation="VectorInvariant", decomp=dec)
-            m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
+            g = dec.local_grid(S.RectilinearGrid, NX, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
+            m = S.ShallowWaterModel(g, formulation=form, decomp=dec)
+            n1, n2 = m.names[:2]
+            m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
             dt = 0.2 * min(g.dx, g.dy) / 4.2
             out[tag + "_ms"] = timeit(lambda: m.time_steps(1, dt), 40)
             # host side: wall time to ENQUEUE 40 steps (no synchronisation inside), one C call per step and one call for all 40
@@ -53,8 +55,8 @@ def main():
             m.synchronize(); m.close(); del m
             torch.cuda.empty_cache()
         out["ring_over_plain"] = out["ring_of_one_ms"] / out["plain_ms"]
-        res[f"4096x{Ny}"] = out
-        print(f"4096x{Ny}", json.dumps(out), flush=True)
+        res[f"{NX}x{Ny}"] = out
+        print(f"{NX}x{Ny}", json.dumps(out), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
         json.dump(res, open(a.out, "w"), indent=1)
