@@ -25,9 +25,9 @@ def _ics():
     return dict(h=hf, u=uf, v=vf, A=Af), Lx, Ly
 
 
-def _build(S, form, dec, strict, overlap=True, group=None):
+def _build(S, form, dec, strict, overlap=True, group=None, deep=False):
     ics, Lx, Ly = _ics()
-    g = dec.local_grid(S.RectilinearGrid, N, x=(0, Lx), y=(0, Ly))
+    g = dec.local_grid(S.RectilinearGrid, N, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo() if deep else (3, 3))
     m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, strict=strict, decomp=dec, group=group, overlap=overlap)
     if form == "VectorInvariant":
         m.set(u=ics["u"], v=ics["v"], h=ics["h"], A=ics["A"])
@@ -36,7 +36,7 @@ def _build(S, form, dec, strict, overlap=True, group=None):
     return m
 
 
-def _worker(rank, world, port, form, strict, out):
+def _worker(rank, world, port, form, strict, out, deep=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -44,7 +44,9 @@ def _worker(rank, world, port, form, strict, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import swmhd_amd as S
-        m = _build(S, form, S.SlabDecomposition(N, world, rank), strict)
+        dec = S.SlabDecomposition(N, world, rank)
+        m = _build(S, form, dec, strict, deep=deep)
+        assert m.grid.Hy == (9 if deep else 3)
         for _ in range(NSTEPS):
             m.time_step(DT)
         m.synchronize()
@@ -57,10 +59,13 @@ def _worker(rank, world, port, form, strict, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("form,strict", [("VectorInvariant", True), ("VectorInvariant", False), ("Conservative", True)])
-def test_two_ranks_on_one_gpu_match_single_domain(swmhd, tmp_path, form, strict):
+@pytest.mark.parametrize("form,strict,deep", [("VectorInvariant", True, False), ("VectorInvariant", False, False), ("Conservative", True, False),
+                                              ("VectorInvariant", True, True)])
+def test_two_ranks_on_one_gpu_match_single_domain(swmhd, tmp_path, form, strict, deep):
+    """deep: slab grids with the 9-row y halo bench.py gives them (SlabDecomposition.ring_halo) on the torch.distributed p2p path, which
+    keeps the per-stage schedule and simply exchanges all 9 rows."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), form, strict, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), form, strict, str(tmp_path), deep), nprocs=world, join=True)
     m = _build(swmhd, form, swmhd.SlabDecomposition(N, 1, 0), strict)
     for _ in range(NSTEPS):
         m.time_step(DT)
