@@ -141,6 +141,35 @@ def test_deep_halo_fast_kernels_thin_and_tall_slabs(rccl_world_of_one, form, dty
             assert np.abs(a[k] - b[k]).max() <= tol * max(np.abs(a[k]).max(), 1.0), (Nx, Ny, k)
 
 
+@pytest.mark.parametrize("Nx,Ny", [(100, 32), (130, 33), (1100, 45), (1101, 45)])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_deep_halo_schedule_awkward_sizes(rccl_world_of_one, Nx, Ny, dtype):
+    """Smallest slab the deep-halo schedule takes (32 rows: the last stage's interior is 8 rows), odd heights and widths, widths
+    on either side of the 1024 columns from which the boundary zones go to the row-marching kernel (odd width: the unpacked fp32
+    kernel); strict build bitwise against the periodic model, fast build within tolerance."""
+    import swmhd_amd as S
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    for strict in (True, False):
+        out = []
+        for ring in (False, True):
+            dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
+            g = dec.local_grid(S.RectilinearGrid, Nx, x=(0, Lx), y=(0, Ly), halo=dec.ring_halo())
+            assert (g.Hy == 9) == ring
+            m = S.ShallowWaterModel(g, 9.81, 1.0, formulation="VectorInvariant", strict=strict, decomp=dec, dtype=dtype)
+            m.set(u=uf, v=vf, h=hf, A=Af)
+            m.time_steps(2, 1e-4); m.time_step(1e-4)
+            out.append(_interior(m))
+            m.close()
+        a, b = out
+        assert np.isfinite(a).all()
+        if strict:
+            assert np.array_equal(a, b)
+        else:
+            tol = 1e-12 if dtype == torch.float64 else 2e-5
+            for k in range(4):
+                assert np.abs(a[k] - b[k]).max() <= tol * max(np.abs(a[k]).max(), 1.0), k
+
+
 def test_deep_halo_schedule_under_real_concurrency(rccl_world_of_one):
     """Hazard check of the deep-halo schedule with launches long enough to overlap on the chip (the 96^2 case above is over before
     the other stream starts): (a) strict kernels, 2048 x 40 and 2048 x 64 slabs, 60 steps in calls of 1 and 20 -- bitwise equal to the
