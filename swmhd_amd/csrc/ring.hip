@@ -123,7 +123,8 @@ template <> struct Api<float> {
     static constexpr auto halo = swmhd_fill_halo_periodic_multi_f32;
 };
 
-// nsteps RK3 steps of one y-slab.  Per stage (X = current state, Y = the other buffer set):
+// nsteps RK3 steps of one y-slab.  Two schedules: the deep-halo one (Hy >= 9, x wrapped on read: ONE exchange per step, described
+// where it is implemented below) and the per-stage one.  Per stage (X = current state, Y = the other buffer set):
 //   main stream : rows [Hy, Ny-Hy) of X -> Y          (need no remote data; the exchange of X is still in flight)
 //   comm stream : ... exchange of X ... ; rows [0,Hy) and [Ny-Hy,Ny) of X -> Y     (one launch, queued behind the exchange)
 //   x wrapped on read : comm: exchange of Y straight after the strips ; comm waits for main's interior ; main waits for the strips
