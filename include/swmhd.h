@@ -181,7 +181,9 @@ int swmhd_fill_halo_f32(float *const *fields, int nf, int Nx, int Ny, int Hx, in
  * first-order upwind and the centred fourth-order advecting velocity to second order (Oceananigans' topologically conditional
  * interpolation, restated; parity UNPINNED), the divergence forcing takes the reference's wall branches, and the tendency of the
  * wall-normal velocity ON the wall (index 1) is whatever the stencil gives: the caller's halo fill resets that line to zero, as
- * Oceananigans' does.  Bounded grids run on the LDS-tiled kernel.  A direction cannot be both Bounded and SWMHD_WRAP-ped.
+ * Oceananigans' does.  Bounded grids run on the LDS-tiled kernel; from ~0.3 Mcell on, the row-marching kernel computes every row with
+ * the periodic formulas first and the LDS-tiled kernel then overwrites the frame of cells near the walls (same results to rounding).
+ * A direction cannot be both Bounded and SWMHD_WRAP-ped.
  * ---------------------------------------------------------------------------------------------- */
 #define SWMHD_CONSERVATIVE 0
 #define SWMHD_VECTOR_INVARIANT 1

@@ -71,6 +71,7 @@ struct TendArgs {
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
     int topo_x, topo_y;   // 0 Periodic, 1 Bounded (wall orders of the reconstructions; the LDS-tiled kernel implements them)
     int leave_room;       // marching kernels: leave ~5 % of the workgroup slots free for another stream's kernels
+    int edge_cols;        // LDS-tiled kernel: only the first and the last two 64-column tile columns (the x-wall frame of a Bounded grid)
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;

@@ -123,6 +123,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.fuse = 0; a.first = 0; a.store_G = 1; a.drop_G = 0; a.dt = a.gamma = a.zeta = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
+    a.edge_cols = 0;
     a.topo_x = (flags & SWMHD_BOUNDED_X) ? SWMHD_BOUNDED : SWMHD_PERIODIC; a.topo_y = (flags & SWMHD_BOUNDED_Y) ? SWMHD_BOUNDED : SWMHD_PERIODIC;
     a.kernel_variant = (flags & SWMHD_TILE_KERNEL) ? 1 : ((flags & SWMHD_MARCH_KERNEL) ? 2 : 0);
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
