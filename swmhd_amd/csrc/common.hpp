@@ -22,6 +22,7 @@ struct OpArgs {
     int j0, j1;  // rows [j0, j1) are computed (0-based)
     int topo_x, topo_y;
     int kernel_variant;  // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
+    int edge_cols;       // LDS-tiled divergence kernel: only tile columns 0, last - 1, last (the x-wall frame of a Bounded grid)
 };
 
 // launchers, one pair per translation unit (fast: reciprocal multiplies + FMA; strict: reference op order,

@@ -31,6 +31,7 @@ int lorentz_common(bool divergence, const T *A, const T *h, T *Fx, T *Fy, int Nx
     a.Nx = Nx; a.Ny = Ny; a.Hx = Hx; a.Hy = Hy; a.sy = (long)sy;
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy;
     a.j0 = j_begin; a.j1 = j_end; a.topo_x = topo_x; a.topo_y = topo_y;
+    a.edge_cols = 0;
     hipStream_t s = (hipStream_t)stream;
     const bool strict = (flags & SWMHD_STRICT) != 0;
     hipError_t e;

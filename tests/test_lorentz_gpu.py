@@ -207,6 +207,32 @@ def test_bounded_wall_branches(swmhd, oracle, topo, dtype, shape):
         assert not np.array_equal(w[I], p[I])      # the wall branches really are exercised
 
 
+@pytest.mark.parametrize("topo", [("Bounded", "Bounded"), ("Bounded", "Periodic"), ("Periodic", "Bounded")])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_bounded_wall_branches_large_grid_hybrid_launch(swmhd, oracle, topo, dtype):
+    """From ~0.9 Mcell on a Bounded grid takes the marching kernel (periodic branch) over every row and the LDS-tiled kernel with
+    the wall branches over the frame near the walls: against the oracle within the fast tolerance everywhere, and bitwise the
+    all-tile launch inside the frame."""
+    Nx, Ny, H = 1300, 800, 3
+    A, h = Hh.random_case(Nx, Ny, H, H, 4242, dtype, periodic=False)
+    g = swmhd.RectilinearGrid(size=(Nx, Ny), x=(0, 0.37 * Nx), y=(0, 0.41 * Ny), halo=(H, H), topology=(topo[0], topo[1], "Flat"))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    f = {"A": swmhd.Field(g, dtype=tdt, data=torch.from_numpy(A).cuda()), "h": swmhd.Field(g, dtype=tdt, data=torch.from_numpy(h).cuda())}
+    code = {"Periodic": oracle.PERIODIC, "Bounded": oracle.BOUNDED}
+    want = oracle.lorentz_divergence(A, h, Nx, Ny, H, H, g.dx, g.dy, topo=(code[topo[0]], code[topo[1]]), nthreads=8)
+    I = g.interior
+    auto = _run(swmhd, "divergence", g, f, strict=False)
+    tile = _run(swmhd, "divergence", g, f, strict=False, kernel="tile")
+    frame = np.zeros((Ny, Nx), dtype=bool)
+    if topo[1] == "Bounded":
+        frame[:8] = True; frame[-8:] = True
+    if topo[0] == "Bounded":
+        frame[:, :64] = True; frame[:, 64 * ((Nx - 1) // 64 - 1):] = True
+    for w, a, t in zip(want, auto, tile):
+        assert np.abs(w[I] - a[I]).max() <= TOL[dtype] * np.abs(w[I]).max()
+        assert np.array_equal(a[I][frame], t[I][frame])
+
+
 def test_error_codes_on_device_pointers(swmhd):
     g = swmhd.RectilinearGrid(size=(16, 16), x=(0, 1), y=(0, 1), halo=(2, 2))
     A, h = swmhd.Field(g), swmhd.Field(g)
