@@ -22,7 +22,7 @@ struct OpArgs {
     int j0, j1;  // rows [j0, j1) are computed (0-based)
     int topo_x, topo_y;
     int kernel_variant;  // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
-    int edge_cols;       // LDS-tiled divergence kernel: only tile columns 0, last - 1, last (the x-wall frame of a Bounded grid)
+    int edge_cols;       // LDS-tiled divergence kernel: only tile column 0 and the last one (or two): the x-wall frame of a Bounded grid
 };
 
 // launchers, one pair per translation unit (fast: reciprocal multiplies + FMA; strict: reference op order,
@@ -72,7 +72,7 @@ struct TendArgs {
     int kernel_variant;   // 0 = by size, 1 = LDS-tiled kernel, 2 = row-marching kernel
     int topo_x, topo_y;   // 0 Periodic, 1 Bounded (wall orders of the reconstructions; the LDS-tiled kernel implements them)
     int leave_room;       // marching kernels: leave ~5 % of the workgroup slots free for another stream's kernels
-    int edge_cols;        // LDS-tiled kernel: only the first and the last two 64-column tile columns (the x-wall frame of a Bounded grid)
+    int edge_cols;        // LDS-tiled kernel: only the first and the last (narrow last: last two) 64-column tile columns -- the x-wall frame of a Bounded grid
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;

@@ -160,7 +160,7 @@ def test_large_bounded_grid_hybrid_launch_matches_oracle_and_tile_kernel(swmhd, 
     if topo[1] == B:
         frame[:8] = True; frame[-8:] = True
     if topo[0] == B:
-        frame[:, :64] = True; frame[:, 64 * ((Nx - 1) // 64 - 1):] = True
+        frame[:, :64] = True; frame[:, 64 * ((Nx - 1) // 64):] = True
     for key in ("auto", "auto_state"):
         for a, t in zip(out[key], out[key.replace("auto", "tile")]):
             if key == "auto":   # (after a whole step the frame has read its rounding-different neighbours: tolerance only)

@@ -227,7 +227,7 @@ def test_bounded_wall_branches_large_grid_hybrid_launch(swmhd, oracle, topo, dty
     if topo[1] == "Bounded":
         frame[:8] = True; frame[-8:] = True
     if topo[0] == "Bounded":
-        frame[:, :64] = True; frame[:, 64 * ((Nx - 1) // 64 - 1):] = True
+        frame[:, :64] = True; frame[:, 64 * ((Nx - 1) // 64):] = True
     for w, a, t in zip(want, auto, tile):
         assert np.abs(w[I] - a[I]).max() <= TOL[dtype] * np.abs(w[I]).max()
         assert np.array_equal(a[I][frame], t[I][frame])
