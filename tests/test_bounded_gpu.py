@@ -168,3 +168,28 @@ def test_large_bounded_grid_hybrid_launch_matches_oracle_and_tile_kernel(swmhd, 
             assert np.abs(a[I] - t[I]).max() <= tol * max(np.abs(t[I]).max(), scale)  # elsewhere: rounding only
     if form == 1 and dtype == np.float64:   # (the vector-invariant marching kernel rounds differently from the tile kernel: proof that it ran)
         assert any(not np.array_equal(a[I], t[I]) for a, t in zip(out["auto"], out["tile"]))
+
+
+def test_bounded_model_graph_replay_equals_eager(swmhd):
+    """HIP-graph replay (capture_graph / time_steps) of a Bounded model on the reference's own grid size: the step is 3 fused stages
+    + 3 boundary-condition fills, all plain launches on the caller's stream; bit-identical to eager stepping, odd leftovers included."""
+    S = swmhd
+    g = S.RectilinearGrid(size=(64, 64), x=(-5, 5), y=(-5, 5), topology=("Periodic", "Bounded", "Flat"))
+    bcs = {"A": S.FieldBoundaryConditions(north=S.GradientBoundaryCondition(-0.05), south=S.GradientBoundaryCondition(-0.05))}
+    ms = []
+    for _ in range(2):
+        m = S.ShallowWaterModel(g, 9.81, 1.0, formulation="VectorInvariant", boundary_conditions=bcs)
+        m.set(u=lambda X, Y: 0.1 * np.exp(-(X ** 2 + Y ** 2)), v=lambda X, Y: 0 * X, h=lambda X, Y: 1 + 0.01 * np.cos(0.3 * X),
+              A=lambda X, Y: 0.05 * np.abs(Y))
+        ms.append(m)
+    a, b = ms
+    dt = 2e-3
+    b.capture_graph(dt)
+    for n in (7, 2, 5):
+        b.time_steps(n, dt)
+        for _ in range(n):
+            a.time_step(dt)
+        a.synchronize(); b.synchronize()
+        for fa, fb in zip(a.fields, b.fields):
+            assert torch.equal(fa.data, fb.data)
+    assert a.iteration == b.iteration == 14
