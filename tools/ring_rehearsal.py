@@ -32,17 +32,28 @@ def main():
     res = {"device": torch.cuda.get_device_name(0), "workload": f"config {a.config} fields on {NX} x Ny slabs, fp64, {form}"}
     for Ny in ((a.only,) if a.only else ((4096, 2048, 1024, 512) if a.config == 3 else (4096, 2048, 1024))):
         ydom = (yc - Ly * Ny / FULL / 2, yc + Ly * Ny / FULL / 2)
-        out = {}
+        out, models = {}, {}
+        import time, statistics
         for tag, ring in (("plain", False), ("ring_of_one", True)):
             dec = S.SlabDecomposition(Ny, 1, 0, force_ring=ring)
             g = dec.local_grid(S.RectilinearGrid, NX, x=cfg["domain"]["x"], y=ydom, halo=dec.ring_halo())
             m = S.ShallowWaterModel(g, formulation=form, decomp=dec)
             n1, n2 = m.names[:2]
             m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
-            dt = 0.2 * min(g.dx, g.dy) / 4.2
-            out[tag + "_ms"] = timeit(lambda: m.time_steps(1, dt), 40)
+            models[tag] = (m, 0.2 * min(g.dx, g.dy) / 4.2)
+            out[tag + "_native_ring"] = m._ring is not None
+        # the two models alternate, 5 rounds of 40 steps each (one C call per step); the MEDIAN of the rounds is reported: box-to-box and
+        # run-to-run differences of a few % would otherwise drown the ring's overhead
+        rounds = {"plain": [], "ring_of_one": []}
+        for r in range(5):
+            for tag in ("plain", "ring_of_one"):
+                m, dt = models[tag]
+                rounds[tag].append(timeit(lambda: m.time_steps(1, dt), 40, spin=60 if r == 0 else 10))
+        for tag in rounds:
+            m, dt = models[tag]
+            out[tag + "_ms"] = statistics.median(rounds[tag])
+            out[tag + "_ms_rounds"] = rounds[tag]
             # host side: wall time to ENQUEUE 40 steps (no synchronisation inside), one C call per step and one call for all 40
-            import time
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(40): m.time_steps(1, dt)
             out[tag + "_enqueue_ms_per_step"] = (time.perf_counter() - t0) / 40 * 1e3
@@ -51,9 +62,11 @@ def main():
             out[tag + "_enqueue_ms_per_step_one_call"] = (time.perf_counter() - t0) / 40 * 1e3
             torch.cuda.synchronize()
             out[tag + "_ms_one_call"] = timeit(lambda: m.time_steps(40, dt), 3, spin=2) / 40
-            out[tag + "_native_ring"] = m._ring is not None
-            m.synchronize(); m.close(); del m
-            torch.cuda.empty_cache()
+        for tag in models:
+            m, _ = models[tag]
+            m.synchronize(); m.close()
+        del models
+        torch.cuda.empty_cache()
         out["ring_over_plain"] = out["ring_of_one_ms"] / out["plain_ms"]
         res[f"{NX}x{Ny}"] = out
         print(f"{NX}x{Ny}", json.dumps(out), flush=True)
