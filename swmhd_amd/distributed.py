@@ -38,21 +38,26 @@ class SlabDecomposition:
                         j_offset=self.j_offset, Ny_global=self.Ny_global)
 
 
-def exchange_y_halos(parents, Ny, Hy, decomp, group=None):
+def exchange_y_halos(parents, Ny, Hy, decomp, group=None, depth=None):
     """Fill the south/north halo rows of every parent tensor in `parents` (shape (Ny+2Hy, W), contiguous) from the ring
     neighbours.  x halos must already be filled (corners travel with the rows).  world_size 1: local periodic copy.
+    `depth` (default Hy) rows next to the interior are exchanged: a grid with the deep 9-row slab halo needs only the stencil's 3
+    when the stages are driven one by one.
     Returns after the exchange has been *enqueued* for CUDA/NCCL tensors (stream-ordered) or completed for CPU/gloo."""
+    d = Hy if depth is None else depth
+    if not (0 < d <= Hy):
+        raise ValueError(f"exchange depth {d} outside (0, Hy = {Hy}]")
     if not decomp.ring:
         for p in parents:
-            p[:Hy].copy_(p[Ny:Ny + Hy])
-            p[Ny + Hy:].copy_(p[Hy:2 * Hy])
+            p[Hy - d:Hy].copy_(p[Ny + Hy - d:Ny + Hy])
+            p[Ny + Hy:Ny + Hy + d].copy_(p[Hy:Hy + d])
         return
     backend = dist.get_backend(group)
     cuda_over_gloo = parents[0].is_cuda and backend == "gloo"   # rehearsal mode: stage the rows through the host
     ops, stash = [], []
     for p in parents:
-        send_s, send_n = p[Hy:2 * Hy], p[Ny:Ny + Hy]            # my southern / northern interior edge rows
-        recv_s, recv_n = p[:Hy], p[Ny + Hy:]                    # my south / north halo rows
+        send_s, send_n = p[Hy:Hy + d], p[Ny + Hy - d:Ny + Hy]   # my southern / northern interior edge rows
+        recv_s, recv_n = p[Hy - d:Hy], p[Ny + Hy:Ny + Hy + d]   # my south / north halo rows (next to the interior)
         if cuda_over_gloo:
             bufs = [send_s.cpu(), send_n.cpu(), torch.empty(recv_s.shape, dtype=p.dtype), torch.empty(recv_n.shape, dtype=p.dtype)]
             stash.append((recv_s, recv_n, bufs))

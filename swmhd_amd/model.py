@@ -299,7 +299,7 @@ class ShallowWaterModel:
     def time_step(self, dt):
         if self._ring is not None:
             return self._ring_steps(dt, 1)
-        g, H = self.grid, self.grid.Hy
+        g, H = self.grid, 3          # strips and per-stage exchange: the stencil's reach, whatever the grid's halo depth
         multi = self.decomp.ring
         overlap = multi and self.overlap and self._comm_stream is not None and g.Ny > 2 * H
         for stage in range(3):
@@ -329,10 +329,10 @@ class ShallowWaterModel:
                 if overlap:
                     self._comm_stream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._comm_stream):
-                        exchange_y_halos([f.data for f in self._raw_fields], g.Ny, H, self.decomp, self.group)
+                        exchange_y_halos([f.data for f in self._raw_fields], g.Ny, g.Hy, self.decomp, self.group, depth=H)
                     self._exchange_in_flight = True
                 else:
-                    exchange_y_halos([f.data for f in self._raw_fields], g.Ny, H, self.decomp, self.group)
+                    exchange_y_halos([f.data for f in self._raw_fields], g.Ny, g.Hy, self.decomp, self.group, depth=H)
         self.clock_time += dt
         self.iteration += 1
 
