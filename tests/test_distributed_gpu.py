@@ -79,3 +79,25 @@ def test_two_ranks_on_one_gpu_match_single_domain(swmhd, tmp_path, form, strict,
     d = m.diagnostics()
     dd = np.load(tmp_path / "diag.npy")
     assert abs(dd[0] - d["total_energy"]) <= 1e-12 * abs(d["total_energy"]) and dd[1] == d["max_abs_A"] and dd[2] == d["min_h"]
+
+
+def test_bench_line_for_two_ranks_sharing_the_gpu():
+    """`python bench.py --gpus 2 --backend gloo` on the one-GPU box: bench.py launches its two workers itself, both on cuda:0, halo rows
+    staged through the host (rehearsal mode) -- everything of the N > 1 bench path except RCCL runs: strong-scaled 4096^2 headline,
+    the weak-scaled `companion` run, max over ranks, one JSON line from rank 0."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "4096^2" in d["metric"] and d["config"]["finite"]
+    assert "4096x2048 cells per GPU" in d["config"]["workload"] and d["value"] > 0
+    c = d["companion"]
+    assert c["scaling"] == "weak" and c["finite"] and "4096x8192" in c["workload"] and c["value"] > 0
+    assert d["roofline"]["cells_per_launch"] < 4096 * 2048       # rank 0's interior launches
