@@ -168,12 +168,14 @@ inline int env_knob(const char *name, int &cache) {   // cache: 0 = not read yet
 // 256 lanes = 1280, but 9 x 128 = 1152).  Rows per segment: the smallest whole number of rounds of resident workgroups
 // (wg_per_cu x CUs slots; ~5 % fewer with leave_room, so that another stream's kernels find room) whose segments are at most
 // 128 rows, but never shorter than ly_min rows.
-// Share of the workgroup slots an interior launch of the slab driver leaves free for the comm stream's kernels, in 64ths (3 = 4.7 %;
-// SWMHD_RING_ROOM overrides: tuning)
-inline int leave_room_64ths() {
+// Share of the workgroup slots an interior launch of the slab driver leaves free for the comm stream's kernels, in 64ths: 3 (4.7 %),
+// and 1 (1.6 %) for slabs of 3072 rows and more -- the boundary work per step is fixed, a long interior launch gives it time enough in
+// few slots, and every slot costs the interior launch its share of the chip (4096 x 4096 ring-of-one step: +1.4-1.9 % over the plain
+// step with 1, +3.7-4.0 % with 3; 4096 x 2048: +4.8-5.2 % vs +4.6-4.7 %; three alternating runs each).  SWMHD_RING_ROOM overrides (tuning).
+inline int leave_room_64ths(int rows) {
     static int cache = 0;
     const int v = env_knob("SWMHD_RING_ROOM", cache);
-    return v > 0 ? (v < 32 ? v : 32) : 3;
+    return v > 0 ? (v < 32 ? v : 32) : (rows >= 3072 ? 1 : 3);
 }
 inline MarchGeometry march_geometry(int Nx, int rows, int xh, const int *nts, const int *wgs, int ncand, int ly_min, bool leave_room,
                                     int force_nt, int force_ly) {
@@ -187,7 +189,7 @@ inline MarchGeometry march_geometry(int Nx, int rows, int xh, const int *nts, co
     }
     if (best < 0) { g.nt = nts[0]; g.nstrips = (Nx + nts[0] - 2 * xh - 1) / (nts[0] - 2 * xh); g.wg_per_cu = wgs[0]; }
     int slots = device_cu_count() * g.wg_per_cu;
-    if (leave_room) slots -= (slots * leave_room_64ths()) / 64;
+    if (leave_room) slots -= (slots * leave_room_64ths(rows)) / 64;
     int LY = 32;
     for (int k = 1; k <= 64; ++k) {
         const int ns = (slots * k) / g.nstrips;
