@@ -58,11 +58,21 @@ def lib():
             f = getattr(_LIB, f"oracle_time_step_{sfx}")
             f.argtypes = [p] * 6 + [C.c_long] + [C.c_int] * 4 + [C.c_long, ct, ct, ct, ct, C.c_int, C.c_int, ct, C.c_int, C.c_int, p, C.c_int]
             f.restype = C.c_int
+            _LIB.oracle_set_variant.argtypes = [C.c_char_p, C.c_double]
+            _LIB.oracle_set_variant.restype = C.c_int
             f = getattr(_LIB, f"oracle_probe_{sfx}")
             f.argtypes = [C.c_int, p, p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, ct, ct,
                           C.c_int, C.c_int]
             f.restype = ct
     return _LIB
+
+
+def set_variant(**kw):
+    """Switch one of the version-dependent choices of oracle/sw_rhs.inc (see oracle_variant_t in swmhd_oracle.c); `reset=1`
+    restores the defaults (= what the product kernels implement).  Sweep / discriminator use only."""
+    for k, v in kw.items():
+        if lib().oracle_set_variant(k.encode(), float(v)):
+            raise KeyError(f"unknown oracle variant {k!r}")
 
 
 def _sfx(a):

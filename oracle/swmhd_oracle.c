@@ -16,6 +16,39 @@
 #include <math.h>
 #include <stddef.h>
 
+/*
+ * Switches over the choices of the un-pinned library where its v0.7x releases differ from one another or where the restatement
+ * could not be checked.  The DEFAULTS are what the product kernels implement and what every parity
+ * test uses; the other values exist for the discriminator sweep against the reference's energy plots (tools/plot_sweep.py,
+ * tests/test_reference_plots.py).  Process-global, set through oracle_set_variant(); not thread-safe against running evaluations.
+ */
+typedef struct {
+    int rbeta_swap;   /* 1: right-biased beta_0 / beta_2 take the end-point forms of the left-biased ones on the same ordered tuples */
+    int js_weights;   /* 1: Jiang-Shu weights C/(beta+eps)^p instead of the Z-WENO ones (zweno = false)                          */
+    int vel_beta;     /* VelocityStencil indicators: 0 mean of beta(Iy u), beta(Ix v); 1 beta of the vorticity itself (VorticityStencil);
+                         2 max of the two; 3 u only (v only for the x-reconstruction ... "tangential"); 4 the other component     */
+    int vhat4;        /* 1: advecting velocity of the vorticity flux by the centred fourth-order interpolant                      */
+    int no_cdivU;     /* 1: tracer tendency without the + c div(U) term                                                            */
+    int weno_exp;     /* exponent of the weights (2)                                                                               */
+    int upwind_cons;  /* 1: vorticity flux in "conservative" order: reconstruct zeta, multiply by the LOCAL interpolated velocity  */
+    double eps;       /* epsilon of the weights (1e-6)                                                                             */
+} oracle_variant_t;
+static oracle_variant_t OV = {0, 0, 0, 0, 0, 2, 0, 1e-6};
+
+#include <string.h>
+int oracle_set_variant(const char *name, double v) {
+    if (!strcmp(name, "reset")) { oracle_variant_t d = {0, 0, 0, 0, 0, 2, 0, 1e-6}; OV = d; return 0; }
+    if (!strcmp(name, "rbeta_swap")) { OV.rbeta_swap = (int)v; return 0; }
+    if (!strcmp(name, "js_weights")) { OV.js_weights = (int)v; return 0; }
+    if (!strcmp(name, "vel_beta")) { OV.vel_beta = (int)v; return 0; }
+    if (!strcmp(name, "vhat4")) { OV.vhat4 = (int)v; return 0; }
+    if (!strcmp(name, "no_cdivU")) { OV.no_cdivU = (int)v; return 0; }
+    if (!strcmp(name, "weno_exp")) { OV.weno_exp = (int)v; return 0; }
+    if (!strcmp(name, "upwind_cons")) { OV.upwind_cons = (int)v; return 0; }
+    if (!strcmp(name, "eps")) { OV.eps = v; return 0; }
+    return 1;
+}
+
 #define REAL double
 #define SFX _f64
 #include "lorentz_ops.inc"

@@ -1,0 +1,137 @@
+"""The runs behind the reference's twelve committed energy plots, as inputs for the oracle (CPU) and the HIP engine (GPU).
+
+The plots (energy_plots/{jacobian,divergence}_formulation/{64x64,128x128}_{two_Gaussians_low_B,two_Gaussians_high_B,low_B_low_U}.png)
+are the only dynamic outputs the reference holds; tests/golden/plot_readings.json is their digitisation.  Set-up of every run:
+jacobian_formulation/SWMHD_example.jl:10-42 / divergence_formulation/divergence_sw_mhd.jl:10-39 -- [-5,5]^2, g = 9.81, f = 1, RK3,
+dt = 0.01, h = 1 -- with the initial conditions the scripts keep as (commented) alternatives:
+  two_Gaussians_low_B   A = 0.1 exp(-((x-0.5)^2+y^2)) - 0.1 exp(-((x+0.5)^2+y^2))   (SWMHD_example.jl:37),  u = v = 0
+  two_Gaussians_high_B  the same with amplitude 0.5                                  (divergence_sw_mhd.jl:33)
+  low_B_low_U           A = -0.05 y, (u, v) = (y, -x) exp(-(x^2+y^2))                (divergence_sw_mhd.jl:34,36-37) with
+                        GradientBoundaryCondition(-0.05) on A at north and south     (:17, SWMHD_example.jl:19): a linear A is not
+                        periodic, and the plots' ME(0) = 0.125 = (1/2) 0.05^2 100 exactly only without the wrap-around jump, so the
+                        run was (Periodic, Bounded, Flat) with those conditions.  Topology is an inference, stated in DESIGN.md.
+Energies: SWMHD_example.jl:67-77 / divergence_sw_mhd.jl:63-74 (np_diagnostics below); the fourth panel is abs(E - E0) * 100."""
+import json
+import os
+
+import numpy as np
+
+G, F, L, DT, H = 9.81, 1.0, 10.0, 0.01, 3
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def two_gaussians(amp):
+    return lambda X, Y: amp * np.exp(-((X - 0.5) ** 2 + Y ** 2)) - amp * np.exp(-((X + 0.5) ** 2 + Y ** 2))
+
+
+ICS = {
+    "two_Gaussians_low_B": dict(A=two_gaussians(0.1), u=None, v=None, topo=(0, 0), gradA=None),
+    "two_Gaussians_high_B": dict(A=two_gaussians(0.5), u=None, v=None, topo=(0, 0), gradA=None),
+    "low_B_low_U": dict(A=lambda X, Y: -0.05 * Y, u=lambda X, Y: Y * np.exp(-(X ** 2 + Y ** 2)),
+                        v=lambda X, Y: -X * np.exp(-(X ** 2 + Y ** 2)), topo=(0, 1), gradA=(None, None, -0.05, -0.05)),
+}
+
+
+def readings():
+    with open(os.path.join(HERE, "golden", "plot_readings.json")) as f:
+        r = json.load(f)
+    return {k: v for k, v in r.items() if not k.startswith("_")}
+
+
+def parse(key):
+    """'jacobian_formulation/128x128_two_Gaussians_low_B' -> (form, N, ic name); form 1 = VectorInvariant + Jacobian forcing"""
+    d, rest = key.split("/")
+    n, ic = rest.split("_", 1)
+    return (1 if d.startswith("jacobian") else 0), int(n.split("x")[0]), ic
+
+
+def np_diagnostics(q1, q2, h, A, Nx, Ny, dx, dy, form, href=1.0, Hh=H):
+    """numpy evaluation of the reference's energy expressions with Oceananigans' operand-location rule (a binary operation of
+    fields at different locations is evaluated at the location of its first operand): KE SWMHD_example.jl:74 (form 1) /
+    divergence_sw_mhd.jl:71 (form 0, literally (1/2)(1/h)(uh^2 + vh^2)); ME :75 / :72 with B_x = -dA/dy / h, B_y = dA/dx / h."""
+    S = lambda a, di, dj: a[Hh + dj:Hh + dj + Ny, Hh + di:Hh + di + Nx]
+    hc = S(h, 0, 0)
+    W = lambda di: S(q1, di, 0) ** 2 + 0.5 * (0.5 * (S(q2, di - 1, 0) ** 2 + S(q2, di, 0) ** 2) + 0.5 * (S(q2, di - 1, 1) ** 2 + S(q2, di, 1) ** 2))
+    wbar = 0.5 * (W(0) + W(1))
+    ke = 0.5 * (1.0 / hc) * wbar if form == 0 else 0.5 * hc * wbar
+    BX = lambda di, dj: -((S(A, di, dj) - S(A, di, dj - 1)) / dy) / (0.5 * (S(h, di, dj - 1) + S(h, di, dj)))
+    BY = lambda di, dj: ((S(A, di, dj) - S(A, di - 1, dj)) / dx) / (0.5 * (S(h, di - 1, dj) + S(h, di, dj)))
+    Z = lambda dj: BX(0, dj) ** 2 + 0.5 * (0.5 * (BY(0, dj - 1) ** 2 + BY(1, dj - 1) ** 2) + 0.5 * (BY(0, dj) ** 2 + BY(1, dj) ** 2))
+    me = 0.5 * hc * (0.5 * (Z(0) + Z(1)))
+    pe = 0.5 * G * (hc - href) ** 2
+    c = dx * dy
+    uw, vs = S(q1, 0, 0), S(q2, 0, 0)
+    if form == 0:      # u = uh / h at uh's faces (divergence_sw_mhd.jl:45-47)
+        uw, vs = uw / (0.5 * (S(h, -1, 0) + hc)), vs / (0.5 * (S(h, 0, -1) + hc))
+    return dict(kinetic_energy=ke.sum() * c, magnetic_energy=me.sum() * c, potential_energy=pe.sum() * c,
+                max_abs_u=np.abs(uw).max(), max_abs_v=np.abs(vs).max(), max_abs_A=np.abs(S(A, 0, 0)).max(), min_h=hc.min())
+
+
+def initial_fields(N, ic, form):
+    """halo-padded parents (q1, q2, h, A) at their staggered nodes, halos NOT yet filled"""
+    d = L / N
+    k = np.arange(-H, N + H)
+    xc, xf = -L / 2 + (k + 0.5) * d, -L / 2 + k * d
+    cc, fc, cf = np.meshgrid(xc, xc), np.meshgrid(xf, xc), np.meshgrid(xc, xf)
+    c = ICS[ic]
+    h = np.ones_like(cc[0])
+    q1 = c["u"](*fc) if c["u"] else np.zeros_like(h)       # h = 1: (uh, vh) = (u, v)
+    q2 = c["v"](*cf) if c["v"] else np.zeros_like(h)
+    return [np.ascontiguousarray(a, dtype=np.float64) for a in (q1, q2, h, c["A"](*cc))], d
+
+
+def run_oracle(key, variant=None, t_end=None, sample=1.0, nthreads=8, oracle=None):
+    """time series {times, kinetic, magnetic, potential, error_x100} of one plotted run on the CPU oracle; variant = dict of
+    oracle_set_variant switches (reset afterwards)"""
+    from oracle import oracle as O
+    O = oracle or O
+    form, N, ic = parse(key)
+    c = ICS[ic]
+    q, d = initial_fields(N, ic, form)
+    topo, grad = c["topo"], c["gradA"]
+    face = [(True, False), (False, True), (False, False), (False, False)]
+    for a, fc, gr in zip(q, face, (None, None, None, grad)):
+        O.fill_halo(a, N, N, H, H, topo=topo, face=fc, grad=gr, dx=d, dy=d)
+    O.set_variant(**(variant or {}))
+    try:
+        nsamp = int(round(sample / DT))
+        nsteps = int(round((t_end if t_end is not None else readings()[key]["times"][-1]) / DT))
+        out = dict(times=[], kinetic=[], magnetic=[], potential=[], total=[])
+        work = None
+
+        def rec(t):
+            dg = np_diagnostics(*q, N, N, d, d, form)
+            out["times"].append(t)
+            for n, k in (("kinetic", "kinetic_energy"), ("magnetic", "magnetic_energy"), ("potential", "potential_energy")):
+                out[n].append(float(dg[k]))
+            out["total"].append(float(dg["kinetic_energy"] + dg["magnetic_energy"] + dg["potential_energy"]))
+        rec(0.0)
+        for s in range(1, nsteps + 1):
+            work = O.time_step(*q, N, N, H, H, d, d, DT, form, 2 - form, G, F, nthreads=nthreads, work=work, topo=topo, gradA=grad)
+            if s % nsamp == 0:
+                rec(s * DT)
+    finally:
+        O.set_variant(reset=1)
+    out["error_x100"] = [abs(e - out["total"][0]) * 100 for e in out["total"]]
+    return out
+
+
+def compare(series, reading, panels=("kinetic", "magnetic", "potential", "error_x100"), slack=1.0, floor=None):
+    """max over the common sample times of |run - plot| / tol per panel, tol = slack * reading tolerance (+ floor[panel])"""
+    res = {}
+    tr = {round(t, 6): i for i, t in enumerate(reading["times"])}
+    for p in panels:
+        if p not in reading:
+            continue
+        worst = (0.0, None)
+        for i, t in enumerate(series["times"]):
+            j = tr.get(round(t, 6))
+            if j is None or reading[p][j] is None:
+                continue
+            v, tol = reading[p][j]
+            tol = slack * tol + (floor or {}).get(p, 0.0)
+            r = abs(series[p][i] - v) / tol
+            if r > worst[0]:
+                worst = (r, t, series[p][i], v, tol)
+        res[p] = worst
+    return res
