@@ -11,7 +11,9 @@
  *     2nd-order convergence).  The reference stores no numeric outputs, so last-bit parity with a Julia run
  *     cannot be pinned here (no Julia toolchain in this image; nothing was denied).
  *   - Base shallow-water RHS + RK3 (sw_rhs.inc; row A9): lives in Oceananigans.jl, which the reference
- *     neither vendors nor pins.  PARITY UNPINNED -- restated from the library's published scheme.
+ *     neither vendors nor pins.  Restated from the library's published scheme and pinned to the reference's
+ *     twelve committed energy plots at plot-reading accuracy (tests/test_reference_plots.py,
+ *     tests/golden/plot_readings.json); not pinned bit-for-bit (no stored numeric outputs, no Julia here).
  */
 #include <math.h>
 #include <stddef.h>
@@ -23,7 +25,8 @@
  * tests/test_reference_plots.py).  Process-global, set through oracle_set_variant(); not thread-safe against running evaluations.
  */
 typedef struct {
-    int rbeta_swap;   /* 1: right-biased beta_0 / beta_2 take the end-point forms of the left-biased ones on the same ordered tuples */
+    int rbeta_mirror; /* 1: right-biased beta_0 / beta_2 as the mirror images of the left-biased ones (textbook Jiang-Shu).  Default 0 =
+                         the library's v0.7x form (end-point forms swapped, not reflected) -- the form the reference's plots pin          */
     int js_weights;   /* 1: Jiang-Shu weights C/(beta+eps)^p instead of the Z-WENO ones (zweno = false)                          */
     int vel_beta;     /* VelocityStencil indicators: 0 mean of beta(Iy u), beta(Ix v); 1 beta of the vorticity itself (VorticityStencil);
                          2 max of the two; 3 u only (v only for the x-reconstruction ... "tangential"); 4 the other component     */
@@ -38,7 +41,7 @@ static oracle_variant_t OV = {0, 0, 0, 0, 0, 2, 0, 1e-6};
 #include <string.h>
 int oracle_set_variant(const char *name, double v) {
     if (!strcmp(name, "reset")) { oracle_variant_t d = {0, 0, 0, 0, 0, 2, 0, 1e-6}; OV = d; return 0; }
-    if (!strcmp(name, "rbeta_swap")) { OV.rbeta_swap = (int)v; return 0; }
+    if (!strcmp(name, "rbeta_mirror")) { OV.rbeta_mirror = (int)v; return 0; }
     if (!strcmp(name, "js_weights")) { OV.js_weights = (int)v; return 0; }
     if (!strcmp(name, "vel_beta")) { OV.vel_beta = (int)v; return 0; }
     if (!strcmp(name, "vhat4")) { OV.vhat4 = (int)v; return 0; }

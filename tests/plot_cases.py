@@ -116,22 +116,66 @@ def run_oracle(key, variant=None, t_end=None, sample=1.0, nthreads=8, oracle=Non
     return out
 
 
-def compare(series, reading, panels=("kinetic", "magnetic", "potential", "error_x100"), slack=1.0, floor=None):
-    """max over the common sample times of |run - plot| / tol per panel, tol = slack * reading tolerance (+ floor[panel])"""
+PE_OFFSET = 0.5 * G * L * L      # 490.5: the 64^2 Jacobian-form plots show mean((1/2) g h^2) Lx Ly instead of (1/2) g (h - 1)^2; with
+                                  # mass conserved the two differ by this constant
+
+
+def compare(series, reading, panels=("kinetic", "magnetic", "potential", "error_x100"), slack=1.0, skip_first=True):
+    """Per panel: the largest |run - plot| / tol over the common sample times and where it occurs.
+    tol = slack * (reading tolerance of the value + reading tolerance of the TIME axis (1.5 px) * local slope of the run)."""
     res = {}
     tr = {round(t, 6): i for i, t in enumerate(reading["times"])}
+    ts = series["times"]
     for p in panels:
         if p not in reading:
             continue
+        xpp = reading[p + "_scale"]["x_per_px"]
         worst = (0.0, None)
-        for i, t in enumerate(series["times"]):
+        for i, t in enumerate(ts):
             j = tr.get(round(t, 6))
-            if j is None or reading[p][j] is None:
+            if j is None or reading[p][j] is None or (skip_first and i == 0):     # t = 0: the drawn line starts inside the first pixel
                 continue
             v, tol = reading[p][j]
-            tol = slack * tol + (floor or {}).get(p, 0.0)
+            if p == "potential" and v > 400:
+                v -= PE_OFFSET
+            lo, hi = max(i - 1, 0), min(i + 1, len(ts) - 1)
+            slope = max(abs(series[p][hi] - series[p][i]), abs(series[p][i] - series[p][lo])) / max(ts[hi] - ts[i], ts[i] - ts[lo], 1e-30)
+            tol = slack * (tol + 1.5 * xpp * slope)
             r = abs(series[p][i] - v) / tol
             if r > worst[0]:
                 worst = (r, t, series[p][i], v, tol)
         res[p] = worst
     return res
+
+
+def run_model(S, key, strict=False, sample=1.0, t_end=None, dtype=None):
+    """The same run through the product: swmhd_amd.ShallowWaterModel on the GPU (fused HIP kernels, RK3 driver)."""
+    import torch
+    form, N, ic = parse(key)
+    c = ICS[ic]
+    topo = tuple("Bounded" if t else "Periodic" for t in c["topo"]) + ("Flat",)
+    g = S.RectilinearGrid(size=(N, N), x=(-L / 2, L / 2), y=(-L / 2, L / 2), topology=topo)
+    bcs = None
+    if c["gradA"]:
+        side = dict(zip(("west", "east", "south", "north"), c["gradA"]))
+        bcs = {"A": S.FieldBoundaryConditions(**{k: S.GradientBoundaryCondition(v) for k, v in side.items() if v is not None})}
+    m = S.ShallowWaterModel(g, G, F, formulation="VectorInvariant" if form == 1 else "Conservative", strict=strict,
+                            dtype=dtype or torch.float64, boundary_conditions=bcs)
+    n1, n2 = m.names[:2]
+    zero = lambda X, Y: np.zeros_like(X)
+    m.set(**{n1: c["u"] or zero, n2: c["v"] or zero, "h": lambda X, Y: np.ones_like(X), "A": c["A"]})
+    nsamp = int(round(sample / DT))
+    nsteps = int(round((t_end if t_end is not None else readings()[key]["times"][-1]) / DT))
+    out = dict(times=[], kinetic=[], magnetic=[], potential=[], total=[])
+
+    def rec(t):
+        d = m.diagnostics()
+        out["times"].append(t)
+        for n, k in (("kinetic", "kinetic_energy"), ("magnetic", "magnetic_energy"), ("potential", "potential_energy"), ("total", "total_energy")):
+            out[n].append(float(d[k]))
+    rec(0.0)
+    for s in range(nsamp, nsteps + 1, nsamp):
+        m.time_steps(nsamp, DT)
+        rec(s * DT)
+    out["error_x100"] = [abs(e - out["total"][0]) * 100 for e in out["total"]]
+    return out

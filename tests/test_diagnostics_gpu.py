@@ -82,21 +82,4 @@ def test_initial_energies_low_B_low_U(swmhd):
     assert abs(d["magnetic_energy"] - 0.125) < 1e-12
 
 
-@pytest.mark.parametrize("form,drift_max", [("VectorInvariant", 0.01), ("Conservative", 0.35)])
-def test_energy_drift_low_B_two_gaussians(swmhd, form, drift_max):
-    """64x64 two_Gaussians_low_B run with the reference's parameters (dt = 0.01, g = 9.81, f = 1, SWMHD_example.jl:21-42) to
-    t = 10: total energy stays within the band the committed plots show by t = 60 (abs(E-E0)*100 <= 1 -> |dE| <= 0.01 for
-    the Jacobian form, <= 0.35 for the divergence form), fields stay finite, A's extrema do not grow (pure advection)."""
-    g = swmhd.RectilinearGrid(size=(64, 64), x=(-5, 5), y=(-5, 5))
-    m = swmhd.ShallowWaterModel(g, G, 1.0, formulation=form)
-    m.set(h=lambda X, Y: np.ones_like(X), A=two_gaussians(0.1))
-    d0 = m.diagnostics()
-    for _ in range(1000):
-        m.time_step(0.01)
-    m.synchronize()
-    d1 = m.diagnostics()
-    assert all(np.isfinite(v) for v in d1.values())
-    assert abs(d1["total_energy"] - d0["total_energy"]) * 100 <= drift_max * 100
-    assert d1["max_abs_A"] <= d0["max_abs_A"] * (1 + 1e-6)
-    assert 0 < d1["kinetic_energy"] < 0.02 and d1["magnetic_energy"] < d0["magnetic_energy"] * 1.001
-    assert 0.9 < d1["min_h"] <= 1.0
+# (The dynamic pins -- KE / ME / PE / |E - E0| time series of all twelve plotted runs -- are tests/test_reference_plots.py.)

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import plot_cases as P
 
-DEFAULT_VARIANTS = ["", "rbeta_swap=1", "js_weights=1", "vel_beta=1", "vel_beta=2", "vel_beta=3", "vel_beta=4", "vhat4=1", "no_cdivU=1",
+DEFAULT_VARIANTS = ["", "rbeta_mirror=1", "js_weights=1", "vel_beta=1", "vel_beta=2", "vel_beta=3", "vel_beta=4", "vhat4=1", "no_cdivU=1",
                     "eps=1e-10", "eps=1e-2", "weno_exp=1"]
 
 
