@@ -64,6 +64,9 @@ def parse(argv=None):
     p.add_argument("--force-ring", action="store_true",
                    help="N=1 rehearsal of the multi-GPU step: y halos through the RCCL ring exchange (sends to self) + overlap")
     p.add_argument("--no-companion", action="store_true", help="N > 1: do not also measure the other scaling mode")
+    p.add_argument("--launch-timeout", type=float, default=540.0,
+                   help="self-launcher (N > 1 without torchrun): wall-clock deadline in seconds for the whole run; on expiry the workers "
+                        "are stopped, the ranks still alive and the tails of their stderr are printed, exit code 124")
     p.add_argument("--rendezvous-only", action="store_true",
                    help="create the process group, barrier, print {'launcher': 'ok', ...} and exit (tests the launcher without a GPU)")
     return p.parse_args(argv)
@@ -72,10 +75,21 @@ def parse(argv=None):
 # ------------------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` with no torchrun around it
 # ------------------------------------------------------------------------------------------------------------------------------
+def _tail(path, n=15):
+    try:
+        with open(path, errors="replace") as f:
+            return "".join(f.readlines()[-n:]).rstrip()
+    except OSError:
+        return ""
+
+
 def self_launch(args):
     """Start N fresh worker processes (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set) BEFORE anything in this process touches the GPU,
-    forward rank 0's stdout (the JSON line), fail if any worker fails.  Never re-execs a GPU-initialised process."""
-    import socket
+    forward rank 0's stdout (the JSON line), fail if any worker fails.  Never re-execs or restarts a GPU-initialised process.
+    A wall-clock deadline (--launch-timeout) bounds the run: a rank stuck in communicator creation or in its first exchange would
+    otherwise block the launcher until the driver's own kill, with nothing written.  Worker stderr goes to per-rank files whose
+    tails are printed on failure (rank 0's is forwarded whole on success)."""
+    import socket, tempfile
     N = args.gpus
     if args.backend == "nccl":
         import torch   # device_count() does not initialise the GPU on this image
@@ -86,25 +100,40 @@ def self_launch(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, errs = [], []
+    logdir = tempfile.mkdtemp(prefix="swmhd_bench_")
     for r in range(N):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    rc = 0
+        errs.append(os.path.join(logdir, f"rank{r}.stderr"))
+        with open(errs[-1], "wb") as ef:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=ef))
+    rc, why = 0, ""
+    deadline = time.monotonic() + args.launch_timeout
     while True:
         codes = [p.poll() for p in procs]
-        bad = [c for c in codes if c not in (None, 0)]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
         if bad:
-            rc = bad[0]
-            for p, c in zip(procs, codes):      # a failed rank leaves the others waiting in a collective: stop exactly those processes
-                if c is None:
-                    p.terminate()
+            rc, why = bad[0][1], f"rank {bad[0][0]} exited with code {bad[0][1]}"
             break
         if all(c == 0 for c in codes):
             break
+        if time.monotonic() > deadline:
+            alive = [r for r, c in enumerate(codes) if c is None]
+            rc, why = 124, f"--launch-timeout {args.launch_timeout:g} s expired with rank(s) {alive} still running"
+            break
         time.sleep(0.05)
+    if rc != 0:   # a failed or stuck rank leaves the others waiting in a collective: stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
     out = procs[0].stdout.read().decode()
     for p in procs:
         try:
@@ -112,9 +141,21 @@ def self_launch(args):
         except subprocess.TimeoutExpired:
             p.kill(); p.wait()
     if rc == 0:
+        sys.stderr.write(open(errs[0], errors="replace").read())
         sys.stdout.write(out); sys.stdout.flush()
     else:
-        print(f"bench.py: a worker failed (exit code {rc}); no result line", file=sys.stderr)
+        print(f"bench.py: {why}; no result line.  Last stderr lines per rank:", file=sys.stderr)
+        for r, e in enumerate(errs):
+            print(f"--- rank {r} (exit {procs[r].returncode}) ---\n{_tail(e)}", file=sys.stderr)
+    for e in errs:
+        try:
+            os.remove(e)
+        except OSError:
+            pass
+    try:
+        os.rmdir(logdir)
+    except OSError:
+        pass
     return rc
 
 
@@ -257,6 +298,9 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
 
+    if os.environ.get("SWMHD_BENCH_TEST_HANG_RANK") == str(rank):      # tests/test_bench_launcher.py: a rank that never arrives
+        print(f"bench.py: rank {rank} sleeping (SWMHD_BENCH_TEST_HANG_RANK)", file=sys.stderr, flush=True)
+        time.sleep(3600)
     import numpy as np
     import torch
     dist = None

@@ -63,6 +63,32 @@ prognostic(model) = (model.solution[1], model.solution[2], model.solution.h, mod
 tendencies(model) = (model.timestepper.Gⁿ[1], model.timestepper.Gⁿ[2], model.timestepper.Gⁿ.h, model.timestepper.Gⁿ.A)
 to_numpy(fields) = permutedims(cat((Array(parent(f))[:, :, 1] for f in fields)...; dims = 3), (3, 2, 1))   # (4, Ny+2H, Nx+2H)
 
+# Which call fills Gⁿ depends on the library vintage.  In the v0.7x releases the reference's `WENO5(vector_invariant = ...)` needs,
+# `update_state!` only fills halos and auxiliary fields; the tendencies are computed inside `time_step!` by
+# `calculate_tendencies!(model)` (Models.ShallowWaterModels).  Later releases renamed it `compute_tendencies!` and moved the call
+# into `update_state!`.  Call it explicitly, whichever exists, and record which branch ran.
+const SWM = Oceananigans.Models.ShallowWaterModels
+function fill_tendencies!(model)
+    update_state!(model)                                # fill_halo_regions! (a no-op on these already-periodic parents)
+    if isdefined(SWM, :calculate_tendencies!)
+        Base.invokelatest(getfield(SWM, :calculate_tendencies!), model)
+        return "Models.ShallowWaterModels.calculate_tendencies!(model)"
+    elseif isdefined(SWM, :compute_tendencies!)
+        f = getfield(SWM, :compute_tendencies!)
+        try
+            Base.invokelatest(f, model, [])             # (model, callbacks) in the releases that have callbacks here
+        catch err
+            err isa MethodError || rethrow()
+            Base.invokelatest(f, model)
+        end
+        return "Models.ShallowWaterModels.compute_tendencies!(model[, callbacks])"
+    elseif isdefined(Oceananigans.TimeSteppers, :calculate_tendencies!)
+        Base.invokelatest(getfield(Oceananigans.TimeSteppers, :calculate_tendencies!), model)
+        return "TimeSteppers.calculate_tendencies!(model)"
+    end
+    error("no calculate_tendencies!/compute_tendencies! found in this Oceananigans: fill Gⁿ by hand and re-run")
+end
+
 for tag in ("vi", "cons")
     model = build(tag)
     q = z["$(tag)_q"]                                   # (4, Ny+2H, Nx+2H)
@@ -70,8 +96,11 @@ for tag in ("vi", "cons")
         size(parent(f))[1:2] == (Nx + 2H, Ny + 2H) || error("parent of field $k is $(size(parent(f))): halo or location mismatch")
         parent(f)[:, :, 1] .= permutedims(q[k, :, :])   # halos included: exactly the bytes the HIP engine was given
     end
-    update_state!(model)                                # fill_halo_regions! (a no-op on these already-periodic parents) + tendencies
-    # after update_state! the timestepper's Gⁿ hold calculate_tendencies!(model) of the initial state
+    global tendency_call = fill_tendencies!(model)      # Gⁿ = tendencies of the initial state
+    for (g, k) in zip(tendencies(model), 1:4)           # a G of zeros would "prove" the restatement wrong: refuse to write it
+        any(!iszero, parent(g)) || error("tendency $k of the $tag model is identically zero after $tendency_call: " *
+                                         "this Oceananigans computes tendencies elsewhere; nothing written")
+    end
     npzwrite(joinpath(GOLDEN, "oceananigans_$(tag)_G.npy"), to_numpy(tendencies(model)))
     for _ in 1:2
         time_step!(model, dt)
@@ -81,6 +110,7 @@ end
 
 open(joinpath(GOLDEN, "oceananigans_version.txt"), "w") do io
     println(io, "julia ", VERSION)
+    println(io, "tendencies filled by: ", tendency_call)
     for (_, p) in Pkg.dependencies()
         p.name in ("Oceananigans", "KernelAbstractions", "NPZ") && println(io, p.name, " ", p.version)
     end

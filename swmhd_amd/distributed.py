@@ -68,3 +68,16 @@ def exchange_y_halos(parents, Ny, Hy, decomp, group=None, depth=None):
         req.wait()
     for recv_s, recv_n, bufs in stash:
         recv_s.copy_(bufs[2]); recv_n.copy_(bufs[3])
+
+
+def agree_rc(rc, group=None, device=None):
+    """The largest return code any rank of `group` holds (0 = every rank succeeded).  Used after a per-rank step that must succeed
+    everywhere or nowhere -- creating the native ring's communicator -- so that a failure on one rank raises on ALL of them instead
+    of leaving the others to block in the first exchange.  world size 1 / no process group: rc itself."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(rc)
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([int(rc)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())

@@ -11,7 +11,7 @@ One `time_step(dt)` == Oceananigans' RK3 `time_step!`: 3 x {calculate_tendencies
 import torch
 
 from . import _lib
-from .distributed import SlabDecomposition, exchange_y_halos
+from .distributed import SlabDecomposition, agree_rc, exchange_y_halos
 from .fields import Field, _SFX, _stream_ptr
 from .grid import Center, Face
 
@@ -111,7 +111,19 @@ class ShallowWaterModel:
         with torch.cuda.device(dev):
             rc = self._L.swmhd_ring_create(ctypes.byref(ring), rccl, self.decomp.world_size, self.decomp.rank,
                                            (ctypes.c_ubyte * _lib.RING_ID_BYTES).from_buffer_copy(raw))
-        _lib.check(rc, "swmhd_ring_create")
+        import os
+        if os.environ.get("SWMHD_TEST_RING_CREATE_FAIL_RANK") == str(self.decomp.rank):     # tests: a rank whose communicator failed
+            if rc == 0:
+                self._L.swmhd_ring_destroy(ring)
+            rc = 4
+        # every rank learns whether ALL communicators exist: a rank that failed raises, and so do its peers (they destroy theirs
+        # first) -- otherwise they would block in the first exchange until the launcher's deadline
+        worst = agree_rc(rc, self.group, dev)
+        if worst != 0:
+            if rc == 0:
+                self._L.swmhd_ring_destroy(ring)
+                raise _lib.SwmhdError(f"swmhd_ring_create failed on another rank (rc {worst}); this rank destroyed its communicator")
+            _lib.check(rc, "swmhd_ring_create")
         self._comm_stream = None      # the ring owns the comm stream of the native path
         return ring
 

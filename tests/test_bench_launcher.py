@@ -34,6 +34,24 @@ def test_failed_worker_fails_the_run_without_a_line():
     assert r.stdout.strip() == ""
 
 
+def test_launcher_deadline_stops_a_rank_that_never_arrives():
+    """a rank stuck before / inside communicator creation: the launcher must not wait for ever (round-2 advisor finding)"""
+    import time
+    e = _env(); e["SWMHD_BENCH_TEST_HANG_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--rendezvous-only", "--launch-timeout", "20"], env=e,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 124 and r.stdout.strip() == ""
+    assert time.time() - t0 < 90
+    assert "still running" in r.stderr and "rank 1" in r.stderr and "SWMHD_BENCH_TEST_HANG_RANK" in r.stderr     # who, and its stderr tail
+
+
+def test_failed_worker_reports_its_stderr_tail():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "no-such-backend", "--rendezvous-only"], env=_env(),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode not in (0, 124) and "--- rank 0" in r.stderr and "--- rank 1" in r.stderr
+
+
 def test_world_size_mismatch_is_an_error_not_an_assert():
     e = _env(); e.update(RANK="0", WORLD_SIZE="3", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rendezvous-only"], env=e, capture_output=True, text=True, timeout=120)

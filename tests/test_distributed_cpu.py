@@ -152,3 +152,27 @@ def test_decomposition_bookkeeping():
         SlabDecomposition(100, 8, 0)
     g = d.local_grid(RectilinearGrid, 4096, x=(-1, 1), y=(-10, 10))
     assert g.Ny == 512 and g.dy == 20 / 4096 and abs(g.yc[3] - (-10 + (1536 + 0.5) * g.dy)) < 1e-12
+
+
+def _worker_agree(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from swmhd_amd.distributed import agree_rc
+        got = [agree_rc(0), agree_rc(4 if rank == 1 else 0), agree_rc(rank)]
+        with open(os.path.join(out, f"agree{rank}.txt"), "w") as f:
+            f.write(" ".join(map(str, got)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_return_codes_are_agreed_across_ranks(tmp_path):
+    """swmhd_ring_create on N ranks: a failure on ONE rank must be seen by all of them (they destroy their communicators and raise
+    together instead of blocking in the first exchange; swmhd_amd/model.py::_create_ring) -- the agreement primitive, over gloo."""
+    world = 3
+    mp.spawn(_worker_agree, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert open(tmp_path / f"agree{r}.txt").read() == "0 4 2"
+    from swmhd_amd.distributed import agree_rc
+    assert agree_rc(7) == 7          # no process group: the rank's own code
