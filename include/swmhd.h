@@ -287,6 +287,13 @@ typedef struct swmhd_ring swmhd_ring;
 int swmhd_ring_available(const char *rccl_path);
 int swmhd_ring_unique_id(const char *rccl_path, void *id128);
 int swmhd_ring_create(swmhd_ring **ring, const char *rccl_path, int nranks, int rank, const void *id128);
+/* Loopback transport for rehearsals and tests on ONE GPU (RCCL refuses two ranks on one device): creates `nranks` rings in this
+ * process, rings[k] = rank k with neighbours (k-1, k+1) mod nranks, whose exchanges copy the neighbours' edge rows device-to-device
+ * on the comm streams with RCCL's rendezvous semantics (a receive waits for the sender's matching exchange, a send for the
+ * receiver to have taken the rows).  Everything else -- swmhd_ring_step_rk3's two schedules, streams, events -- is the code the
+ * RCCL ring runs.  Drive every ring from its OWN host thread (an exchange blocks on the host until the neighbours have enqueued
+ * theirs, at most `timeout_s` seconds (<= 0: 60), then SWMHD_ECOMM).  Each ring is destroyed with swmhd_ring_destroy. */
+int swmhd_ring_create_loopback(swmhd_ring **rings, int nranks, double timeout_s);
 int swmhd_ring_destroy(swmhd_ring *ring);
 const char *swmhd_ring_last_error(const swmhd_ring *ring);
 void *swmhd_ring_comm_stream(const swmhd_ring *ring);   /* the ring's hipStream_t */
@@ -314,7 +321,13 @@ int swmhd_ring_exchange_y_f32(swmhd_ring *ring, float *const *fields, int nfield
  * per step): stage k computes interior rows [3,9,12][k] .. Ny - [3,9,12][k] on `stream` and the boundary zones
  * [-6,-3,0][k] .. [3,9,12][k] (and the mirror image at the top) on the comm stream behind the exchange.  `stream` waits for the comm
  * stream once per step instead of once per stage, and a thin slab is bound by its interior launches rather than by the chain
- * exchange -> strips -> exchange.  Entry / exit conditions are the same with "y halos" meaning all Hy rows. */
+ * exchange -> strips -> exchange.  Entry / exit conditions are the same with "y halos" meaning all Hy rows.
+ * Reproducibility against the single-domain run: SWMHD_STRICT slabs are bit-identical to it (every row is the same arithmetic
+ * whoever computes it; tests/test_loopback_gpu.py, 2 and 3 slabs).  Fast builds are NOT: a row may be computed by a different kernel
+ * variant than in the single-domain launch (interior launches pick the row-marching or the LDS-tiled kernel by slab size, the
+ * boundary zones take the row-marching kernel whenever Nx >= 1024), and the deep-halo schedule's redundantly computed rows need not
+ * equal the owner's copy in the last bits -- differences of the fast-kernel rounding (<= 1e-13 of the term scale per evaluation),
+ * deterministic from run to run. */
 int swmhd_ring_step_rk3_f64(swmhd_ring *ring, double *const *q, double *const *q_alt, double *const *Ga, double *const *Gb,
                             int Nx, int Ny, int Hx, int Hy, int64_t stride_y, double dx, double dy,
                             double g, double f, int formulation, int lorentz, double dt, int nsteps,

@@ -7,7 +7,7 @@ from . import _lib
 from .grid import RectilinearGrid, Periodic, Bounded, Flat, Center, Face, GradientBoundaryCondition, FieldBoundaryConditions
 from .fields import Field
 from .operators import lorentz_force_func, div_lorentz
-from .model import ShallowWaterModel, VectorInvariantFormulation, ConservativeFormulation
+from .model import ShallowWaterModel, loopback_rings, VectorInvariantFormulation, ConservativeFormulation
 from .distributed import SlabDecomposition, exchange_y_halos
 
 __all__ = ["RectilinearGrid", "Periodic", "Bounded", "Flat", "Center", "Face", "Field", "GradientBoundaryCondition", "FieldBoundaryConditions",

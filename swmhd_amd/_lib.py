@@ -91,6 +91,8 @@ def _declare(lib):
     lib.swmhd_ring_unique_id.restype = i
     lib.swmhd_ring_create.argtypes = [C.POINTER(p), C.c_char_p, i, i, p]
     lib.swmhd_ring_create.restype = i
+    lib.swmhd_ring_create_loopback.argtypes = [C.POINTER(p), i, C.c_double]
+    lib.swmhd_ring_create_loopback.restype = i
     lib.swmhd_ring_destroy.argtypes = [p]
     lib.swmhd_ring_destroy.restype = i
     lib.swmhd_ring_last_error.argtypes = [p]
@@ -111,7 +113,7 @@ EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry"] 
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
         "fill_halo", "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",
         "ring_exchange_y", "ring_step_rk3")] + [
-    "swmhd_ring_" + name for name in ("available", "unique_id", "create", "destroy", "last_error", "comm_stream", "join", "time_launches",
+    "swmhd_ring_" + name for name in ("available", "unique_id", "create", "create_loopback", "destroy", "last_error", "comm_stream", "join", "time_launches",
                                       "launch_times")]
 RING_ID_BYTES = 128
 

@@ -11,8 +11,12 @@
 // Python harness) so that libswmhd.so itself carries no link-time dependency on it; single-GPU users never touch it.
 #include "common.hpp"
 #include "../../include/swmhd.h"
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <rccl/rccl.h>
 #include <string>
@@ -56,11 +60,42 @@ bool load_rccl(const char *path, RcclApi &api, std::string &err) {
     return true;
 }
 
+// ---- loopback transport ---------------------------------------------------------------------------------------------------------
+// K rings in ONE process on ONE GPU (RCCL refuses two ranks per device): the exchange of ring r copies its neighbours' edge rows
+// into its own halo rows with hipMemcpyAsync on its comm stream, with the rendezvous semantics RCCL gives a grouped send/recv:
+//   a receive completes only after the sender has reached the matching exchange   (wait for the peer's "rows ready" event)
+//   a send completes only after the receiver has taken the rows                     (wait for the peer's "consumed" event)
+// so that the real driver (ring_step) runs with north != south, every ring on its own pair of streams.  Events can only be waited
+// for once they have been recorded, hence a HOST-side rendezvous as well: exchange number k of a ring blocks until its neighbours
+// have enqueued theirs -- the rings must be driven from one host thread each, as RCCL ranks are driven from one process each.  A
+// neighbour that does not arrive within the hub's timeout ends the exchange with SWMHD_ECOMM instead of blocking for ever.
+struct LoopHub {
+    static constexpr int MAXF = 8, SLOTS = 4;
+    struct Post {
+        unsigned long seq = 0;                 // number of exchanges this rank has posted (rows ready)
+        unsigned long done = 0;                // number of exchanges whose receives this rank has enqueued (rows consumed)
+        const char *send_s[SLOTS][MAXF] = {}, *send_n[SLOTS][MAXF] = {};
+        size_t bytes[SLOTS] = {};
+        int nf[SLOTS] = {};
+        hipEvent_t ready[SLOTS] = {}, consumed[SLOTS] = {};
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Post> post;
+    double timeout_s = 60.0;
+    explicit LoopHub(int n) : post(n) {}
+    ~LoopHub() {
+        for (auto &p : post)
+            for (int k = 0; k < SLOTS; ++k) { if (p.ready[k]) (void)hipEventDestroy(p.ready[k]); if (p.consumed[k]) (void)hipEventDestroy(p.consumed[k]); }
+    }
+};
+
 }  // namespace
 
 struct swmhd_ring {
     RcclApi api;
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LoopHub> hub;    // loopback transport (swmhd_ring_create_loopback); comm stays NULL then
     int nranks = 1, rank = 0, south = 0, north = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_comm = nullptr;
@@ -90,11 +125,88 @@ template <> constexpr ncclDataType_t nccl_type<float>() { return ncclFloat32; }
 // One grouped launch: for every field, northern edge rows -> north neighbour's south halo, southern edge rows -> south
 // neighbour's north halo.  Issue order (send_n, recv_s, send_s, recv_n per field) is what makes the 1- and 2-rank rings,
 // where both neighbours are the same peer, pair up correctly: RCCL matches sends and receives of a peer in issue order.
+// The same exchange through the loopback hub (see LoopHub): post my edge rows, copy my neighbours' into my halos, wait until mine were taken.
+int loopback_exchange(swmhd_ring *r, const char *const *send_s, const char *const *send_n, char *const *recv_s, char *const *recv_n,
+                      int nf, size_t bytes, hipStream_t s) {
+    LoopHub &h = *r->hub;
+    if (nf > LoopHub::MAXF) return SWMHD_EINVAL;
+    hipError_t e;
+    unsigned long k;
+    int slot;
+    {   // (1) rows ready: everything enqueued on s so far precedes the neighbours' reads
+        std::unique_lock<std::mutex> lk(h.mu);
+        LoopHub::Post &me = h.post[r->rank];
+        k = me.seq + 1; slot = (int)(k % LoopHub::SLOTS);
+        if (!me.ready[slot] && (e = hipEventCreateWithFlags(&me.ready[slot], hipEventDisableTiming)) != hipSuccess) return hipfail(r, "loopback event", e);
+        if (!me.consumed[slot] && (e = hipEventCreateWithFlags(&me.consumed[slot], hipEventDisableTiming)) != hipSuccess) return hipfail(r, "loopback event", e);
+        if ((e = hipEventRecord(me.ready[slot], s)) != hipSuccess) return hipfail(r, "loopback record", e);
+        for (int f = 0; f < nf; ++f) { me.send_s[slot][f] = send_s[f]; me.send_n[slot][f] = send_n[f]; }
+        me.bytes[slot] = bytes; me.nf[slot] = nf;
+        me.seq = k;
+    }
+    h.cv.notify_all();
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::duration<double>(h.timeout_s);
+    auto wait_for = [&](auto pred, const char *what) {
+        std::unique_lock<std::mutex> lk(h.mu);
+        if (!h.cv.wait_until(lk, deadline, pred)) {
+            r->err = std::string("loopback exchange ") + std::to_string(k) + " of rank " + std::to_string(r->rank) + ": " + what +
+                     " (every ring of the hub must be driven from its own host thread, and all of them must make the same calls)";
+            return false;
+        }
+        return true;
+    };
+    // (2) receives: my south halo <- the south neighbour's northern edge rows; my north halo <- the north neighbour's southern ones
+    const int peers[2] = {r->south, r->north};
+    for (int side = 0; side < 2; ++side) {
+        const int p = peers[side];
+        if (!wait_for([&] { return h.post[p].seq >= k; }, "a neighbour did not reach its matching exchange")) return SWMHD_ECOMM;
+        hipEvent_t ready; const char *src[LoopHub::MAXF]; size_t pbytes; int pnf;
+        {
+            std::unique_lock<std::mutex> lk(h.mu);
+            const LoopHub::Post &pp = h.post[p];
+            ready = pp.ready[slot]; pbytes = pp.bytes[slot]; pnf = pp.nf[slot];
+            for (int f = 0; f < nf && f < pnf; ++f) src[f] = side == 0 ? pp.send_n[slot][f] : pp.send_s[slot][f];
+        }
+        if (pbytes != bytes || pnf != nf) { r->err = "loopback exchange: neighbour posted a different message (fields / bytes)"; return SWMHD_ECOMM; }
+        if ((e = hipStreamWaitEvent(s, ready, 0)) != hipSuccess) return hipfail(r, "loopback wait", e);
+        for (int f = 0; f < nf; ++f)
+            if ((e = hipMemcpyAsync(side == 0 ? recv_s[f] : recv_n[f], src[f], bytes, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+                return hipfail(r, "loopback copy", e);
+    }
+    {   // (3) rows consumed
+        std::unique_lock<std::mutex> lk(h.mu);
+        LoopHub::Post &me = h.post[r->rank];
+        if ((e = hipEventRecord(me.consumed[slot], s)) != hipSuccess) return hipfail(r, "loopback record", e);
+        me.done = k;
+    }
+    h.cv.notify_all();
+    // (4) my sends complete when both neighbours have taken my rows: later work on s may overwrite them
+    for (int side = 0; side < 2; ++side) {
+        const int p = peers[side];
+        if (!wait_for([&] { return h.post[p].done >= k; }, "a neighbour did not take the rows sent to it")) return SWMHD_ECOMM;
+        hipEvent_t consumed;
+        { std::unique_lock<std::mutex> lk(h.mu); consumed = h.post[p].consumed[slot]; }
+        if ((e = hipStreamWaitEvent(s, consumed, 0)) != hipSuccess) return hipfail(r, "loopback wait", e);
+    }
+    return SWMHD_OK;
+}
+
 template <typename T>
 int exchange(swmhd_ring *r, T *const *fields, int nf, int Nx, int Ny, int Hx, int Hy, int64_t sy, hipStream_t s) {
     if (!r || !fields || nf <= 0) return SWMHD_EINVAL;
     if (Nx <= 0 || Ny < Hy || Hy <= 0 || sy < (int64_t)Nx + 2 * Hx) return SWMHD_EINVAL;
     const size_t count = (size_t)Hy * (size_t)sy;   // Hy full rows (the pitch padding of the last row travels too: harmless)
+    if (r->hub) {
+        if (nf > LoopHub::MAXF) return SWMHD_EINVAL;
+        const char *ss[LoopHub::MAXF], *sn[LoopHub::MAXF]; char *rs[LoopHub::MAXF], *rn[LoopHub::MAXF];
+        for (int f = 0; f < nf; ++f) {
+            T *p = fields[f];
+            if (!p) return SWMHD_EINVAL;
+            ss[f] = (const char *)(p + (size_t)Hy * sy); sn[f] = (const char *)(p + (size_t)Ny * sy);
+            rs[f] = (char *)p; rn[f] = (char *)(p + (size_t)(Ny + Hy) * sy);
+        }
+        return loopback_exchange(r, ss, sn, rs, rn, nf, count * sizeof(T), s);
+    }
     ncclResult_t rc = r->api.GroupStart();
     if (rc != ncclSuccess) return fail(r, "ncclGroupStart", rc);
     for (int f = 0; f < nf; ++f) {
@@ -328,6 +440,34 @@ int swmhd_ring_create(swmhd_ring **out, const char *rccl_path, int nranks, int r
     if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_comm, hipEventDisableTiming);
     if (e != hipSuccess) { swmhd_ring_destroy(r); return -(int)e; }
     *out = r;
+    return SWMHD_OK;
+}
+
+int swmhd_ring_create_loopback(swmhd_ring **out, int nranks, double timeout_s) {
+    if (!out || nranks < 1 || nranks > 64) return SWMHD_EINVAL;
+    std::shared_ptr<LoopHub> hub;
+    try { hub = std::make_shared<LoopHub>(nranks); } catch (...) { return SWMHD_EINVAL; }
+    if (timeout_s > 0) hub->timeout_s = timeout_s;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int k = 0; k < nranks; ++k) out[k] = nullptr;
+    for (int k = 0; k < nranks; ++k) {
+        swmhd_ring *r = new (std::nothrow) swmhd_ring;
+        hipError_t e = r ? hipSuccess : hipErrorOutOfMemory;
+        if (r) {
+            r->hub = hub; r->nranks = nranks; r->rank = k;
+            r->south = (k + nranks - 1) % nranks; r->north = (k + 1) % nranks;
+            e = hipStreamCreateWithPriority(&r->comm_stream, hipStreamNonBlocking, hi);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_main, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&r->ev_comm, hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            if (r) swmhd_ring_destroy(r);
+            for (int j = 0; j < k; ++j) { swmhd_ring_destroy(out[j]); out[j] = nullptr; }
+            return -(int)e;
+        }
+        out[k] = r;
+    }
     return SWMHD_OK;
 }
 

@@ -20,10 +20,20 @@ RK3_GAMMA = (8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0)
 RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 
 
+def loopback_rings(nranks, timeout_s=60.0):
+    """`nranks` swmhd_ring handles of the in-process loopback transport (swmhd_ring_create_loopback): rank k's exchange copies the
+    edge rows of ranks k-1 and k+1 (mod nranks) on the same GPU with RCCL's rendezvous semantics.  Pass handle k as
+    `ShallowWaterModel(..., decomp=SlabDecomposition(Ny, nranks, k), ring=handle)` and drive each model from its own thread."""
+    import ctypes
+    arr = (ctypes.c_void_p * nranks)()
+    _lib.check(_lib.lib().swmhd_ring_create_loopback(arr, nranks, float(timeout_s)), "swmhd_ring_create_loopback")
+    return [ctypes.c_void_p(arr[k]) for k in range(nranks)]
+
+
 class ShallowWaterModel:
     def __init__(self, grid, gravitational_acceleration=9.81, coriolis_f=1.0, formulation=VectorInvariantFormulation,
                  lorentz_forcing=True, dtype=torch.float64, device="cuda", strict=False, decomp=None, group=None,
-                 overlap=True, fused=True, kernel="auto", fuse_halo=True, native_ring=True, boundary_conditions=None):
+                 overlap=True, fused=True, kernel="auto", fuse_halo=True, native_ring=True, boundary_conditions=None, ring=None):
         self.grid, self.g, self.f = grid, float(gravitational_acceleration), float(coriolis_f)
         self.formulation = formulation
         self.form_code = _lib.VECTOR_INVARIANT if formulation == VectorInvariantFormulation else _lib.CONSERVATIVE
@@ -74,8 +84,14 @@ class ShallowWaterModel:
             raise _lib.SwmhdError("ShallowWaterModel runs on the GPU only (no CPU fallback)")
         # y-slab ring: the native RCCL ring (swmhd_ring_*) when the process group is RCCL; torch.distributed p2p otherwise
         # (gloo rehearsals).  The ring's step driver needs the fused stage kernel and a slab taller than its two strips.
+        # `ring`: a swmhd_ring handle created by the caller -- one of swmhd_ring_create_loopback's (loopback_rings below): several
+        # slabs of one domain in ONE process on one GPU, each driven from its own host thread and stream.  The model owns it.
         self._ring = None
-        if self.decomp.ring and native_ring and fused and grid.Ny > 2 * grid.Hy:
+        if ring is not None:
+            if not (self.decomp.ring and fused and grid.Ny > 2 * grid.Hy):
+                raise _lib.SwmhdError("ring= needs a ring decomposition, the fused stage kernel and a slab taller than its two strips")
+            self._ring, self._comm_stream = ring, None
+        elif self.decomp.ring and native_ring and fused and grid.Ny > 2 * grid.Hy:
             self._ring = self._create_ring()
 
     def _create_ring(self):
