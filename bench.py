@@ -31,9 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_COPY_GBS = 6290.0          # the same guide's measured copy rate: every fraction is quoted against both (BASELINE.md sections 3-4)
 TEND_BYTES_PER_CELL = 64       # read u,v,h,A + write 4 tendencies, fp64
 STAGE_BYTES_PER_CELL = (96, 128, 96)   # what the three FUSED stage launches move: + new state; + G- read; last stage stores no G
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 VALU_NS_PER_WAVE_INST = 2.05   # one fp64 wave-instruction per 2.05 ns per SIMD (tools/valu_probe.hip: 4 cycles at ~1.95 GHz under load)
 
 CONFIGS = {
@@ -226,8 +227,37 @@ def companion_run(args, world, rank, dist, scaling):
             "finite": finite, "timing": "as the headline: barrier + synchronize on both sides, max over ranks"}
 
 
+def box_probe(torch, _lib):
+    """What THIS box sustains right now, measured in-process right after the timed region: the HBM rate of a plain two-array copy
+    (torch's copy kernel, 1 GiB read + 1 GiB written) and the fp64 issue rate of a SIMD under load (swmhd_probe_fp64_issue).  The boxes
+    of the pool differ by several per cent in both; kernel fractions are quoted against these as well as against the spec figures."""
+    import ctypes
+    out = {}
+    src = torch.empty(1 << 27, dtype=torch.float64, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for _ in range(20):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    out["hbm_copy_GBps"] = 2 * src.numel() * 8 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out["hbm_copy_what"] = "torch copy of a 1-GiB fp64 array (bytes read + written / time), 20 launches in one event pair"
+    ns = ctypes.c_float(0)
+    scratch = torch.zeros(8, dtype=torch.float64, device="cuda")
+    rc = _lib.lib().swmhd_probe_fp64_issue(scratch.data_ptr(), ctypes.byref(ns), torch.cuda.current_stream().cuda_stream)
+    if rc == 0 and ns.value > 0:
+        out["fp64_ns_per_wave_instruction"] = ns.value
+        out["fp64_shader_MHz_under_load"] = 4000.0 / ns.value
+        out["fp64_what"] = "swmhd_probe_fp64_issue: 3 waves per SIMD of independent fma chains; 4 cycles per wave-instruction on a 16-lane SIMD"
+    del src, dst
+    return out
+
+
 def committed(name):
-    """A JSON file under profiles/r02 (or None) plus whether it was collected at the kernel sources that are running now."""
+    """A JSON file under profiles/r03 (or None) plus whether it was collected at the kernel sources that are running now."""
     from swmhd_amd import _lib
     path = os.path.join(PROFILE_DIR, name)
     if not os.path.exists(path):
@@ -238,6 +268,29 @@ def committed(name):
            "running_kernel_source_hash": now}
     src["status"] = "current" if d.get("kernel_source_hash") == now else "stale: kernel sources changed since it was collected"
     return (d if src["status"] == "current" else None), src
+
+
+def parity_block(args):
+    """Achieved errors of the running kernels against the oracle / the reference's plots, from the files the GPU tests write
+    (tests/test_fullsize_gpu.py -> fullsize_parity.json, tests/test_reference_plots.py -> plot_parity.jsonl), echoed only while
+    they were collected at the running kernel sources."""
+    out = {"bar": "strict kernels: bit-identical to the CPU oracle (every entry point, fp64 and fp32, whole RK3 steps); fast kernels: "
+                  "max|dG| <= 1e-13 (fp64) / 1e-4 (fp32) x max(max|G|, S), S = the largest term summed into the output "
+                  "(include/swmhd.h, 'Tolerances'); oracle pinned to the reference's 12 energy plots at reading accuracy",
+           "oracle_pin": "tests/test_reference_plots.py + tests/golden/plot_readings.json"}
+    fp, src = committed("fullsize_parity.json")
+    out["fullsize_source"] = src
+    if fp:
+        key = {3: "config3", 4: "config4_slab", 5: "config5_slab"}.get(args.config, "config3") + "/" + args.dtype
+        rows = {k: v for k, v in fp.items() if k.startswith(key) and isinstance(v, dict)}
+        worst_scale = max((f["err_over_scale"] for v in rows.values() for f in v.values() if isinstance(f, dict) and "err_over_scale" in f), default=None)
+        worst_maxg = max((f["err_over_maxG"] for v in rows.values() for f in v.values() if isinstance(f, dict) and "err_over_maxG" in f), default=None)
+        out["fast_vs_oracle_this_workload"] = {"cases": sorted(rows), "worst_err_over_term_scale": worst_scale, "worst_err_over_max_abs_G": worst_maxg}
+    pp, psrc = committed("plot_parity.json")
+    out["plots_source"] = psrc
+    if pp:
+        out["plots"] = {"runs": pp.get("runs"), "worst_ratio_to_reading_tolerance": pp.get("worst_ratio"), "slack_allowed": pp.get("slack")}
+    return out
 
 
 def cpu_model():
@@ -252,13 +305,14 @@ def cpu_model():
 
 def cpu_baseline(args, cfg, form, dx, dy, dt):
     """The oracle's RK3 step (C restatement: the reference's per-cell Lorentz functions with their unshared composition + the
-    restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 512 x 256 periodic block at the
-    workload's dx, dy and fields, stepped until the time budget is used -- on all cores of the box's share, then on ONE thread."""
+    restated Oceananigans RHS) on the host cores, on a bounded sample of the same workload: a 2048 x 1024 periodic block at the
+    workload's dx, dy and fields (2.1 Mcell, 16 arrays of 17 MB: not cache-resident, like the workload), stepped until the time
+    budget is used -- on all cores of the box's share, then on ONE thread."""
     import numpy as np
     from oracle import oracle as O
     import swmhd_amd as S
     cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16)   # the box's CPU share for one GPU
-    Nx, Ny = 512, 256
+    Nx, Ny = 2048, 1024
     g = S.RectilinearGrid(size=(Nx, Ny), x=(-Nx * dx / 2, Nx * dx / 2), y=(-Ny * dy / 2, Ny * dy / 2))
     fcode = 1 if form == "VectorInvariant" else 0
     names = [("u", ("Face", "Center")), ("v", ("Center", "Face")), ("h", ("Center", "Center")), ("A", ("Center", "Center"))]
@@ -270,7 +324,7 @@ def cpu_baseline(args, cfg, form, dx, dy, dt):
     def rate(nthreads, budget):
         work = O.time_step(*q, Nx, Ny, 3, 3, dx, dy, dt, fcode, 2 - fcode, nthreads=nthreads)   # warm
         t0 = time.perf_counter(); reps = 0
-        while time.perf_counter() - t0 < budget:
+        while time.perf_counter() - t0 < budget or reps < 2:
             O.time_step(*q, Nx, Ny, 3, 3, dx, dy, dt, fcode, 2 - fcode, nthreads=nthreads, work=work); reps += 1
         return Nx * Ny * reps / (time.perf_counter() - t0) / 1e6, reps
 
@@ -354,6 +408,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = t.item()
     finite = all(torch.isfinite(f.data).all().item() for f in m.fields)
+    box = box_probe(torch, _lib) if (rank == 0 and world == 1) else None      # right after the timed region: clocks are settled
     companion = None
     if (world > 1 or args.force_ring) and args.scaling is None and args.n is None and not args.no_companion:
         # (--force-ring: one rank, both workloads coincide -- it only rehearses this code path on a one-GPU box)
@@ -402,6 +457,8 @@ def main():
             kname = "k_tendency_vi_march" if form == "VectorInvariant" else "k_tendency_cons_march"
             roof = {"bound": "hbm", "kernel": kname + " (fused RHS of the 4 prognostic fields incl. Lorentz force + RK3 substep)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "frac_of_measured_copy_6290": achieved / HBM_COPY_GBS,
+                    "frac_of_this_box_copy": (achieved / box["hbm_copy_GBps"]) if box else None,
                     "formula": f"achieved = {tend_bytes} B/cell (SURVEY 8(d): 4 fields read + 4 tendencies written) x cells_per_launch / avg_launch_ms",
                     "algorithmic_bytes_per_launch": tend_bytes * kcells, "cells_per_launch": kcells,
                     "avg_launch_ms": kern_ms, "launches_timed": len(ms),
@@ -409,6 +466,8 @@ def main():
                     "fused_stage": {"bytes_per_cell_stage_1_2_3": [b * bpe // 8 for b in STAGE_BYTES_PER_CELL],
                                     "mean_bytes_per_launch": fused_bytes, "achieved": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                     "frac": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "frac_of_measured_copy_6290": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                                    "frac_of_this_box_copy": (fused_bytes / (kern_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
                                     "what": "bytes the fused stage launches really move (new state written, G- read in stages 2-3, no G "
                                             "store in stage 3); `achieved` above stays on the 64-B tendency figure"},
                     "whole_step_GBps_on_320B": sum(STAGE_BYTES_PER_CELL) * bpe / 8 * cells_global * args.steps / wall / 1e9}
@@ -432,11 +491,12 @@ def main():
                 waves = geo["threads"] // 64
                 wave_rows = geo["nstrips"] * waves * krows
                 valu = {"source": vsrc, "wave_rows_per_launch": wave_rows, "simds": geo["cus"] * 4,
-                        "ns_per_wave_instruction_per_simd": VALU_NS_PER_WAVE_INST,
+                        "ns_per_wave_instruction_per_simd": (box or {}).get("fp64_ns_per_wave_instruction", VALU_NS_PER_WAVE_INST),
+                        "ns_source": "measured in this run (box.fp64_ns_per_wave_instruction)" if (box or {}).get("fp64_ns_per_wave_instruction") else "tools/valu_probe.hip (2.05)",
                         "formula": "floor_ms = valu_insts_per_wave_row x wave_rows_per_launch / simds x ns_per_wave_instruction"}
                 if vp and default_workload:
                     ipr = vp["valu_insts_per_wave_row"]
-                    floor_ms = ipr * wave_rows / (geo["cus"] * 4) * VALU_NS_PER_WAVE_INST * 1e-6
+                    floor_ms = ipr * wave_rows / (geo["cus"] * 4) * valu["ns_per_wave_instruction_per_simd"] * 1e-6
                     valu.update({"valu_insts_per_wave_row": ipr, "floor_ms": floor_ms, "frac_of_floor": floor_ms / kern_ms})
                     stream_ms = fused_bytes / 5.1e12 * 1e3     # tools/stream_probe2.hip: what this access pattern streams at
                     roof["binding_bound"] = "fp64-valu" if floor_ms >= stream_ms else "hbm-streaming"
@@ -445,6 +505,8 @@ def main():
                                                   f"{tend_bytes * kcells / 8e12 * 1e3:.3f} ms")
                 roof["valu"] = valu
             line["roofline"] = roof
+        if box:
+            line["box"] = box
 
         def timed_launches(fn, n_spin, K):
             """K back-to-back launches inside ONE event pair (settled clocks: n_spin launches first)."""
@@ -467,9 +529,19 @@ def main():
             out = (S.Field(g, dtype=dtype), S.Field(g, dtype=dtype))
             op_ms = timed_launches(lambda: op(g, fld, out=out, strict=args.strict), 300, 50)
             op_bytes = 4 * bpe * cells
+            per = []                                   # the same launch timed one by one (events without the system-scope fence)
+            for _ in range(50):
+                ea, eb = _lib.TimingEvent(), _lib.TimingEvent()
+                ea.record(); op(g, fld, out=out, strict=args.strict); eb.record()
+                per.append((ea, eb))
+            torch.cuda.synchronize()
+            per = sorted(a.elapsed_time(b) for a, b in per)
             opk = "k_lorentz_jacobian_march" if form == "VectorInvariant" else "k_lorentz_divergence_march"
             line["lorentz_operator"] = {"kernel": opk, "bound": "hbm", "avg_launch_ms": op_ms, "achieved": op_bytes / (op_ms * 1e-3) / 1e9,
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "frac_of_measured_copy_6290": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                                        "frac_of_this_box_copy": (op_bytes / (op_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
+                                        "per_launch_ms_min_median_max": [per[0], per[len(per) // 2], per[-1]],
                                         "algorithmic_bytes_per_launch": op_bytes, "timing": "50 back-to-back launches inside one HIP event pair",
                                         "rocprof_avg_launch_ms": (ks or {}).get(opk + "_mean_ms") if default_workload else None,
                                         "rocprof_source": ksrc if default_workload else None}
@@ -480,7 +552,10 @@ def main():
             line["tendency_only_launch"] = {"what": "calculate_tendencies! alone (no fused substep): exactly the 64 B/cell of SURVEY 8(d)",
                                             "bound": "hbm", "avg_launch_ms": t_ms, "achieved": t_bytes / (t_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                             "unit": "GB/s", "frac": t_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            "frac_of_measured_copy_6290": t_bytes / (t_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                                            "frac_of_this_box_copy": (t_bytes / (t_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
                                             "algorithmic_bytes_per_launch": t_bytes, "timing": "50 back-to-back launches inside one HIP event pair"}
+        line["parity"] = parity_block(args)
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args, cfg, form, g.dx, g.dy, dt)
         json_out.write(json.dumps(line) + "\n")

@@ -79,6 +79,9 @@ int swmhd_event_create(void **event);
 int swmhd_event_record(void *event, void *stream);
 int swmhd_event_elapsed_ms(void *start, void *stop, float *ms);
 int swmhd_event_destroy(void *event);
+/* Measurement hook: nanoseconds one fp64 wave-instruction occupies a SIMD right now (three waves per SIMD, independent fma chains:
+ * 4 cycles of the shader clock the box holds under fp64 load).  Synchronises `stream`.  scratch: >= 8 bytes of device memory. */
+int swmhd_probe_fp64_issue(double *scratch, float *ns_per_wave_instruction, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Jacobian-form Lorentz force.   Replaces lorentz_force_func_x / lorentz_force_func_y

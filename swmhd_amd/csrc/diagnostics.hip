@@ -127,3 +127,48 @@ template hipError_t launch_diagnostics<float>(const float *, const float *, cons
                                               float, float, float, int, double *, double *, hipStream_t);
 
 }  // namespace swmhd
+
+// ---- measurement hook: what does the fp64 vector ALU of this box sustain right now? ------------------------------------------------
+// Three waves per SIMD (the stage kernels' occupancy), four independent fma chains each: one wave-instruction leaves a 16-lane SIMD
+// every 4 cycles, so ns per wave-instruction = 4 / (shader clock under fp64 load).  bench.py prints it beside the kernel times: the
+// boxes of a pool differ in the clock they hold under load, and the VALU floor of the stage kernels scales with this number.
+namespace swmhd {
+namespace {
+__global__ __launch_bounds__(256) void k_fp64_issue_probe(double *out, double a, double b, int iters) {
+    double x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = threadIdx.x * 1e-3 + c;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = __builtin_fma(x[c], a, b);
+    }
+    const double s = (x[0] + x[1]) + (x[2] + x[3]);
+    if (s == 12345.678) out[0] = s;     // (never true: keeps the chains alive)
+}
+}  // namespace
+}  // namespace swmhd
+
+extern "C" int swmhd_probe_fp64_issue(double *scratch, float *ns_per_wave_instruction, void *stream) {
+    if (!scratch || !ns_per_wave_instruction) return 1;   // SWMHD_EINVAL
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        return 1;
+    hipStream_t s = (hipStream_t)stream;
+    const int W = 3, iters = 4000, blocks = cus * W;   // 4 waves per workgroup = one per SIMD, W workgroups per CU
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return 1;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return 1; }
+    hipLaunchKernelGGL(swmhd::k_fp64_issue_probe, dim3(blocks), dim3(256), 0, s, scratch, 1.0000001, 1e-9, iters);   // warm
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(swmhd::k_fp64_issue_probe, dim3(blocks), dim3(256), 0, s, scratch, 1.0000001, 1e-9, iters);
+    (void)hipEventRecord(e1, s);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return -(int)e;
+    *ns_per_wave_instruction = (float)(ms * 1e6 / ((double)iters * 8 * 4 * W));
+    return 0;
+}

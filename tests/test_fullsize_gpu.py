@@ -9,7 +9,7 @@ C-ABI) against the CPU oracle on all host threads -- once on the initial conditi
 
 Tolerance (stated, asserted, and the achieved error is recorded in gpurun_out/fullsize_parity.json):
     max|G_hip - G_oracle| <= TOL * max(max|G|, S),   TOL = 1e-13 (fp64), 2e-5 (fp32 operators), 1e-4 (fp32 tendencies)
-(achieved on MI355X, profiles/r02/fullsize_parity.json: <= 5e-15 in fp64, <= 5e-7 in fp32, relative to max(max|G|, S))
+(achieved on MI355X, profiles/r03/fullsize_parity.json: <= 5e-15 in fp64, <= 5e-7 in fp32, relative to max(max|G|, S))
 S is the magnitude of the largest TERM summed into the tendency (flux / dx, g h / dx, ...): rounding errors scale with the terms,
 not with their sum, and at these resolutions the sum is often orders of magnitude smaller than its terms (config 3: the mass
 fluxes u h / dx are ~650 while G_h = -div(u h) is ~3e-4, so one ulp of a flux is 2e-10 of max|G_h| in fp64 and 0.15 in fp32 -- the

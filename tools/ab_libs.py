@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """Same-call A/B of two builds of libswmhd.so: alternates `tools/stage_times.py` between the libraries (fresh process each, SWMHD_LIB_PATH)
-for R rounds and prints the per-stage medians.   usage: python tools/ab_libs.py libA.so libB.so [rounds] [N] [-- extra stage_times args]"""
+for R rounds and prints the per-stage medians.   usage: python tools/ab_libs.py libA.so libB.so [libC.so ...] [rounds] [N] [tool.py]   (SWMHD_FORM=Conservative for the other model)"""
 import os, re, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [os.path.abspath(sys.argv[1]), os.path.abspath(sys.argv[2])]
-rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-N = sys.argv[4] if len(sys.argv) > 4 else "4096"
-tool = sys.argv[5] if len(sys.argv) > 5 else "stage_times.py"
+libs = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+rounds = int(rest[0]) if len(rest) > 0 else 3
+N = rest[1] if len(rest) > 1 else "4096"
+tool = rest[2] if len(rest) > 2 else "stage_times.py"
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:

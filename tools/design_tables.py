@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Rewrite the generated tables of DESIGN.md section 5 (between the <!-- configs:begin/end --> and <!-- benchlines:begin/end --> markers)
-from profiles/r02/configs.json and profiles/r02/bench_*.json, so that the prose never drifts from the committed measurements."""
+from profiles/r03/configs.json and profiles/r03/bench_*.json, so that the prose never drifts from the committed measurements."""
 import json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r02")
+P = os.path.join(ROOT, "profiles", "r03")
 d = json.load(open(os.path.join(P, "configs.json")))
 rows = {k: v for k, v in d.items() if isinstance(v, dict) and "grid" in v}
 g = lambda k: (rows[k]["lorentz_operator_us"], rows[k]["lorentz_operator_GBps"] / 1e3, rows[k]["tendency_kernel_us"], rows[k]["rk3_step_ms"],
@@ -28,7 +28,7 @@ B = {f: json.loads(open(os.path.join(P, f + ".json")).read().strip().splitlines(
      ("bench_default", "bench_cons", "bench_ring", "bench_c5f32", "bench_c5f64", "bench_c4")}
 v = lambda f: f"{B[f]['value'] / 1e3:.1f} ({B[f]['ms_per_step']:.3f} ms)"
 tr = B["bench_default"]["roofline"].get("traffic")
-lines = (f"`bench.py` lines (`profiles/r02/bench_*.json`): default {v('bench_default')}"
+lines = (f"`bench.py` lines (`profiles/r03/bench_*.json`): default {v('bench_default')}"
          + (f", `traffic` {tr / 1e9:.2f} GB per launch = {tr / (sum((96, 128, 96)) / 3 * 4096 * 4096):.2f}× the 96/128/96-byte mean the fused stages move" if tr else "")
          + f"; `--formulation Conservative` {v('bench_cons')}; `--force-ring` {v('bench_ring')} — ring of one rank through RCCL, deep-halo schedule"
          + (f", its `companion` run {B['bench_ring']['companion']['ms_per_step']:.3f} ms" if "companion" in B["bench_ring"] else "")

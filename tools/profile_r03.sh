@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 passes behind the numbers bench.py prints (run on the GPU box; raw CSVs land in gpurun_out/prof_r02/, summarise them
-# afterwards with tools/profile_summary.py, which writes profiles/r02/*.json together with the kernel-source hash).
+# rocprofv3 passes behind the numbers bench.py prints (run on the GPU box; raw CSVs land in gpurun_out/prof_r03/, summarise them
+# afterwards with tools/profile_summary.py, which writes profiles/r03/*.json together with the kernel-source hash).
 # Kernel trace and every --pmc set are SEPARATE runs (counters never share a run with a trace domain other than the kernel trace).
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/prof_r02
+O=$R/gpurun_out/prof_r03
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp

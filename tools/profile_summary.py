@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Turn the raw rocprofv3 CSVs of tools/profile_r02.sh (gpurun_out/prof_r02/) into the small JSON / CSV summaries under
-profiles/r02/ that bench.py reads back.  Every file records the kernel-source hash (swmhd_amd._lib.source_hash) and the git HEAD it
+"""Turn the raw rocprofv3 CSVs of tools/profile_r03.sh (gpurun_out/prof_r03/) into the small JSON / CSV summaries under
+profiles/r03/ that bench.py reads back.  Every file records the kernel-source hash (swmhd_amd._lib.source_hash) and the git HEAD it
 was collected at; bench.py echoes a value only while the hash still matches the kernels that are running.
 
-    python tools/profile_summary.py [--raw gpurun_out/prof_r02] [--out profiles/r02] [--steps 100]
+    python tools/profile_summary.py [--raw gpurun_out/prof_r03] [--out profiles/r03] [--steps 100]
 
 Counters: SQ_* are summed over all waves of a dispatch; FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte
 requests at 64 bytes for wide coalesced reads (MI355X_MICROARCH.md, HBM section), so it is doubled.
@@ -48,8 +48,8 @@ def mean(v):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--raw", default=os.path.join(ROOT, "gpurun_out", "prof_r02"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02"))
+    ap.add_argument("--raw", default=os.path.join(ROOT, "gpurun_out", "prof_r03"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03"))
     ap.add_argument("--steps", type=int, default=100, help="timed steps of the --stats run (the last 3*steps stage launches)")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -61,7 +61,7 @@ def main():
         shutil.copy(st, os.path.join(a.out, "fullstep_kernel_stats.csv"))
         rows = list(csv.DictReader(open(st)))
         out = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --steps 100 --warmup 20",
-               **provenance("tools/profile_r02.sh + tools/profile_summary.py"), "kernels": {}}
+               **provenance("tools/profile_r03.sh + tools/profile_summary.py"), "kernels": {}}
         for r in rows:
             k, mode = kernel_key(r["Name"])
             if not k:
@@ -91,7 +91,7 @@ def main():
     so = os.path.join(a.raw, "ops", "ops_kernel_stats.csv")
     if os.path.exists(so):
         shutil.copy(so, os.path.join(a.out, "operators_kernel_stats.csv"))
-        out = {"command": "rocprofv3 --kernel-trace --stats -- python3 tools/time_ops.py 4096", **provenance("tools/profile_r02.sh + tools/profile_summary.py")}
+        out = {"command": "rocprofv3 --kernel-trace --stats -- python3 tools/time_ops.py 4096", **provenance("tools/profile_r03.sh + tools/profile_summary.py")}
         for r in csv.DictReader(open(so)):
             k, _ = kernel_key(r["Name"])
             if k and k.startswith("k_lorentz"):
@@ -108,7 +108,7 @@ def main():
         acc = counters(pv)
         g = _lib_geometry(geo)
         out = {"command": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS -- python3 bench.py --steps 3 --warmup 1",
-               **provenance("tools/profile_r02.sh + tools/profile_summary.py"), "launch_geometry": g, "by_stage": {}}
+               **provenance("tools/profile_r03.sh + tools/profile_summary.py"), "launch_geometry": g, "by_stage": {}}
         per_row = []
         for (k, mode), d in sorted(acc.items()):
             if not k.startswith("k_tendency") or mode is None:
@@ -135,7 +135,7 @@ def main():
     if os.path.exists(pw):
         acc = counters(pw)
         out = {"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 3 --warmup 1",
-               **provenance("tools/profile_r02.sh + tools/profile_summary.py"), "by_stage": {}}
+               **provenance("tools/profile_r03.sh + tools/profile_summary.py"), "by_stage": {}}
         for (k, mode), d in sorted(acc.items()):
             if not k.startswith("k_tendency") or mode is None:
                 continue
@@ -153,7 +153,7 @@ def main():
     if os.path.exists(pf) and os.path.exists(pwr):
         fa, wa = counters(pf), counters(pwr)
         out = {"command": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1",
-               **provenance("tools/profile_r02.sh + tools/profile_summary.py"),
+               **provenance("tools/profile_r03.sh + tools/profile_summary.py"),
                "note": "KiB counters; FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B); per launch", "by_stage": {}}
         tot = []
         for key in sorted(fa):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Ring-of-ONE rehearsal of the multi-GPU step at strong-scaled slab sizes (one GPU: every send goes to self through RCCL, everything
 but the xGMI hop is real): RK3 step time through the native ring driver vs the plain periodic single-GPU step of the same slab.
-    python tools/ring_rehearsal.py [--out profiles/r02/ring_rehearsal.json]"""
+    python tools/ring_rehearsal.py [--out profiles/r03/ring_rehearsal.json]"""
 import argparse, json, os, socket, sys
 import torch
 import torch.distributed as dist

@@ -2,7 +2,7 @@
 """Measure every BASELINE.json configuration that fits one GPU plus the strong-scaling slabs of the 4096^2 grid,
 and write a JSON summary:  config 2 (1024^2 divergence), config 3 (4096^2 Jacobian, the headline), the per-GPU slabs of config 4
 (8192 x 1024 divergence) and config 5 (16384 x 2048 Jacobian, fp64 and fp32), and 4096 x {2048, 1024, 512} slabs of config 3.
-    python tools/run_configs.py [--out profiles/r02/configs.json] [--only name,name]"""
+    python tools/run_configs.py [--out profiles/r03/configs.json] [--only name,name]"""
 import argparse, json, os, sys
 import numpy as np
 import torch

@@ -4,10 +4,12 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 import swmhd_amd as S
 from swmhd_amd import configs
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cfg = configs.config3_bickley()
+FORM = __import__('os').environ.get("SWMHD_FORM", "VectorInvariant")      # SWMHD_FORM=Conservative: config 4's fields on the same grid
+cfg = configs.config3_bickley() if FORM == "VectorInvariant" else configs.config4_two_gaussians()
 g = S.RectilinearGrid(size=(N, N), x=cfg["domain"]["x"], y=cfg["domain"]["y"])
-m = S.ShallowWaterModel(g, formulation="VectorInvariant", kernel=(sys.argv[2] if len(sys.argv) > 2 else "auto"), lorentz_forcing=(len(sys.argv) <= 3 or sys.argv[3] != "nolorentz"))
-m.set(u=cfg["u"], v=cfg["v"], h=lambda X, Y: cfg["h"](X, Y) + 0 * X, A=cfg["A"])
+m = S.ShallowWaterModel(g, formulation=FORM, kernel=(sys.argv[2] if len(sys.argv) > 2 else "auto"), lorentz_forcing=(len(sys.argv) <= 3 or sys.argv[3] != "nolorentz"))
+n1, n2 = m.names[:2]
+m.set(**{n1: cfg["u"], n2: cfg["v"], "h": lambda X, Y: cfg["h"](X, Y) + 0 * X, "A": cfg["A"]})
 for _ in range(60): m.time_step(1e-4)   # (device clocks settle after ~30 ms of load)
 m.tendency_events = []
 torch.cuda.synchronize()
