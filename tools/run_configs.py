@@ -32,7 +32,7 @@ def run(name, Nx, Ny, cfg, form, dtype, ydom=None):
     out = (S.Field(g, dtype=dtype), S.Field(g, dtype=dtype))
     fld = {"A": m.solution["A"], "h": m.solution["h"]}
     bpe = 8 if dtype == torch.float64 else 4
-    t_op = timeit(lambda: op(g, fld, out=out), 30, 100)
+    t_op = timeit(lambda: op(g, fld, out=out), 50, 300)     # (300 launches first: the first ~40 ms of a process run 10-20 % slow)
     t_tend = timeit(m.calculate_tendencies, 20)
     t_step = timeit(lambda: m.time_steps(1, dt), 20)
     cells = Nx * Ny
