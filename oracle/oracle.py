@@ -20,7 +20,7 @@ PERIODIC, BOUNDED = 0, 1
 PROBES = {name: k for k, name in enumerate(
     ["jac_Bx", "jac_By", "jacobian_x", "jacobian_y", "lorentz_force_func_x", "lorentz_force_func_y",
      "div_Bx", "div_By", "div_hBx", "div_hBy", "lorentz_flux_hBx_bx", "lorentz_flux_hBy_bx",
-     "lorentz_flux_hBx_by", "lorentz_flux_hBy_by", "div_lorentz_x", "div_lorentz_y"])}
+     "lorentz_flux_hBx_by", "lorentz_flux_hBy_by", "div_lorentz_x", "div_lorentz_y", "test_jacobian_x", "test_jacobian_y"])}
 
 
 def build(force=False):

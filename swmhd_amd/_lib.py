@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SWMHD_LIB_PATH") or os.path.join(_HERE, "libswmhd.so")   # (the override: A/B timing of two builds, tools/ab_libs.py)
+LIB_PATH = os.path.join(_HERE, "libswmhd.so")
 _LIB = None
 
 STRICT = 1

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(swmhd):
 
 def test_version_and_strerror(swmhd):
     L = swmhd._lib.lib()
-    assert L.swmhd_version() == 200
+    assert L.swmhd_version() == 300
     assert b"RCCL" in L.swmhd_strerror(4)
     assert b"success" in L.swmhd_strerror(0)
     assert b"halo" in L.swmhd_strerror(2)

@@ -192,3 +192,31 @@ def test_halo_requirements(oracle):
     oracle.lorentz_jacobian(A, h, 8, 8, 2, 2, 1.0, 1.0)
     with pytest.raises(ValueError):
         oracle.lorentz_divergence(A, h, 8, 8, 2, 2, 1.0, 1.0)
+
+
+def test_discrete_jacobian_against_the_analytic_gaussian(oracle):
+    """test_jacobian.jl:16-24,45-63: the discrete Jacobian stencils applied to (A, dA/dx) at (xf, yc) and (A, dA/dy) at (xc, yf) against
+    the closed forms for A = exp(-x^2 - y^2) on [-5,5]^2, N = 50 .. 400; the script fits the order of the max-norm error (2)."""
+    errs = []
+    for N in (50, 100, 200, 400):
+        xc, xf, d = Hh.coords(N, 10.0, 3)
+        X, Y = np.meshgrid(xc, xc)
+        A = np.ascontiguousarray(np.exp(-X ** 2 - Y ** 2))          # A(i,j,k,grid,x,y) evaluated from the extended coordinate vectors
+        h = np.ones_like(A)
+        ex = ey = 0.0
+        idx = range(1, N + 1, max(1, N // 50))                     # the probe is per point: sample the grid, always incl. the centre band
+        for j in idx:
+            for i in idx:
+                x, y = xf[i - 1 + 3], xc[j - 1 + 3]
+                e = np.exp(-x * x - y * y)
+                exact = (-2 * x * e) * (4 * x * y * e) - ((4 * x * x - 2) * e) * (-2 * y * e)       # dA_x dA_xy - dA_xx dA_y  (:57-58)
+                ex = max(ex, abs(oracle.probe("test_jacobian_x", A, h, i, j, N, N, 3, 3, d, d) - exact))
+                x, y = xc[i - 1 + 3], xf[j - 1 + 3]
+                e = np.exp(-x * x - y * y)
+                exact = (-2 * x * e) * ((4 * y * y - 2) * e) - (4 * x * y * e) * (-2 * y * e)       # dA_x dA_yy - dA_yx dA_y  (:59-60)
+                ey = max(ey, abs(oracle.probe("test_jacobian_y", A, h, i, j, N, N, 3, 3, d, d) - exact))
+        errs.append((ex, ey))
+    E = np.array(errs)
+    order = np.log2(E[:-1] / E[1:])
+    assert np.all(order > 1.8) and np.all(order < 2.3), (E, order)
+    assert np.all(E[-1] < 2e-3), E

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Same-call A/B of two builds of libswmhd.so: alternates `tools/stage_times.py` between the libraries (fresh process each, SWMHD_LIB_PATH)
+"""Same-call A/B of two builds of libswmhd.so: alternates `tools/stage_times.py` between the libraries (fresh process each, SWMHD_LIBRARY)
 for R rounds and prints the per-stage medians.   usage: python tools/ab_libs.py libA.so libB.so [libC.so ...] [rounds] [N] [tool.py]   (SWMHD_FORM=Conservative for the other model)"""
 import os, re, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +11,7 @@ tool = rest[2] if len(rest) > 2 else "stage_times.py"
 res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), N], env=dict(os.environ, SWMHD_LIB_PATH=l),
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), N], env=dict(os.environ, SWMHD_LIBRARY=l),
                              capture_output=True, text=True).stdout.strip()
         print(os.path.basename(l), out, flush=True)
         m = re.search(r"\[([\d., ]+)\].*step ms: ([\d.]+)", out)

@@ -14,15 +14,15 @@ j1, c4 = g("config3_1024sq_jacobian"), g("config4_slab_8192x1024_divergence")
 c5, c5f = g("config5_slab_16384x2048_jacobian_f64"), g("config5_slab_16384x2048_jacobian_f32")
 table = f"""| configuration (SURVEY §8(d)) | dtype | Lorentz operator | tendency kernel (unfused) | RK3 step | Gcell-steps/s |
 |---|---|---|---|---|---|
-| config2 1024² divergence uniformBx | f64 | {c2[0]:.0f} µs | {c2[2]:.0f} µs | {c2[3]:.3f} ms | **{c2[4]:.1f}** (r1: 6.9) |
-| config3 4096² jacobian bickley | f64 | {c3[0]:.0f} µs ({c3[1]:.1f} TB/s; 101–107 µs outside this run) | {c3[2]:.0f} µs | {c3[3]:.3f} ms | **{c3[4]:.1f}** (other boxes 12.9–13.8) |
+| config2 1024² divergence uniformBx | f64 | {c2[0]:.0f} µs | {c2[2]:.0f} µs | {c2[3]:.3f} ms | **{c2[4]:.1f}** |
+| config3 4096² jacobian bickley | f64 | {c3[0]:.0f} µs ({c3[1]:.1f} TB/s) | {c3[2]:.0f} µs | {c3[3]:.3f} ms | **{c3[4]:.1f}** |
 | config3 strong-scaling slab 4096×2048 | f64 | {s2[0]:.0f} µs | {s2[2]:.0f} µs | {s2[3]:.3f} ms | {s2[4]:.1f} |
 | config3 strong-scaling slab 4096×1024 | f64 | {s1[0]:.0f} µs | {s1[2]:.0f} µs | {s1[3]:.3f} ms | {s1[4]:.1f} |
-| config3 strong-scaling slab 4096×512 | f64 | {s5[0]:.0f} µs | {s5[2]:.0f} µs | {s5[3]:.3f} ms | **{s5[4]:.1f} = {100 * s5[4] / c3[4]:.0f} % of the 4096² per-cell rate** (r1 geometry: 81 %) |
-| 1024² jacobian (vector-invariant) | f64 | {j1[0]:.0f} µs | {j1[2]:.0f} µs | {j1[3]:.3f} ms | {j1[4]:.1f} (r1 kernels: 8.1) |
-| config4 slab 8192×1024 divergence | f64 | {c4[0]:.0f} µs ({c4[1]:.1f} TB/s) | {c4[2]:.0f} µs | {c4[3]:.3f} ms | **{c4[4]:.1f}** (r1: 11.8) |
+| config3 strong-scaling slab 4096×512 | f64 | {s5[0]:.0f} µs | {s5[2]:.0f} µs | {s5[3]:.3f} ms | **{s5[4]:.1f} = {100 * s5[4] / c3[4]:.0f} % of the 4096² per-cell rate** |
+| 1024² jacobian (vector-invariant) | f64 | {j1[0]:.0f} µs | {j1[2]:.0f} µs | {j1[3]:.3f} ms | {j1[4]:.1f} |
+| config4 slab 8192×1024 divergence | f64 | {c4[0]:.0f} µs ({c4[1]:.1f} TB/s) | {c4[2]:.0f} µs | {c4[3]:.3f} ms | **{c4[4]:.1f}** |
 | config5 slab 16384×2048 jacobian | f64 | {c5[0]:.0f} µs ({c5[1]:.1f} TB/s) | {c5[2]:.0f} µs | {c5[3]:.3f} ms | {c5[4]:.1f} |
-| config5 slab 16384×2048 jacobian | f32 | {c5f[0]:.0f} µs ({c5f[1]:.1f} TB/s; r02 start 139) | {c5f[2]:.0f} µs | {c5f[3]:.3f} ms | **{c5f[4]:.1f} = {c5f[4] / c5[4]:.2f}× fp64** (r1: 18.9) |
+| config5 slab 16384×2048 jacobian | f32 | {c5f[0]:.0f} µs ({c5f[1]:.1f} TB/s) | {c5f[2]:.0f} µs | {c5f[3]:.3f} ms | **{c5f[4]:.1f} = {c5f[4] / c5[4]:.2f}× fp64** |
 """
 B = {f: json.loads(open(os.path.join(P, f + ".json")).read().strip().splitlines()[-1]) for f in
      ("bench_default", "bench_cons", "bench_ring", "bench_c5f32", "bench_c5f64", "bench_c4")}
