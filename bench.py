@@ -245,6 +245,11 @@ def box_probe(torch, _lib):
     e1.record(); torch.cuda.synchronize()
     out["hbm_copy_GBps"] = 2 * src.numel() * 8 * 20 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     out["hbm_copy_what"] = "torch copy of a 1-GiB fp64 array (bytes read + written / time), 20 launches in one event pair"
+    gb = ctypes.c_float(0)
+    if _lib.lib().swmhd_probe_copy(dst.data_ptr(), src.data_ptr(), src.numel() * 8, 20, ctypes.byref(gb), torch.cuda.current_stream().cuda_stream) == 0:
+        out["hbm_copy_oneshot_GBps"] = gb.value
+        out["hbm_copy_oneshot_what"] = ("swmhd_probe_copy: one 16-byte element per thread, workgroups in address order -- the best case of the box; "
+                                        "persistent kernels (torch's copy, hipMemcpy, anything that carries state along a direction) reach ~20 % less")
     ns = ctypes.c_float(0)
     scratch = torch.zeros(8, dtype=torch.float64, device="cuda")
     rc = _lib.lib().swmhd_probe_fp64_issue(scratch.data_ptr(), ctypes.byref(ns), torch.cuda.current_stream().cuda_stream)
@@ -459,6 +464,7 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "frac_of_measured_copy_6290": achieved / HBM_COPY_GBS,
                     "frac_of_this_box_copy": (achieved / box["hbm_copy_GBps"]) if box else None,
+                    "frac_of_this_box_oneshot_copy": (achieved / box["hbm_copy_oneshot_GBps"]) if (box and "hbm_copy_oneshot_GBps" in box) else None,
                     "formula": f"achieved = {tend_bytes} B/cell (SURVEY 8(d): 4 fields read + 4 tendencies written) x cells_per_launch / avg_launch_ms",
                     "algorithmic_bytes_per_launch": tend_bytes * kcells, "cells_per_launch": kcells,
                     "avg_launch_ms": kern_ms, "launches_timed": len(ms),
@@ -468,6 +474,7 @@ def main():
                                     "frac": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "frac_of_measured_copy_6290": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                                     "frac_of_this_box_copy": (fused_bytes / (kern_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
+                                    "frac_of_this_box_oneshot_copy": (fused_bytes / (kern_ms * 1e-3) / 1e9 / box["hbm_copy_oneshot_GBps"]) if (box and "hbm_copy_oneshot_GBps" in box) else None,
                                     "what": "bytes the fused stage launches really move (new state written, G- read in stages 2-3, no G "
                                             "store in stage 3); `achieved` above stays on the 64-B tendency figure"},
                     "whole_step_GBps_on_320B": sum(STAGE_BYTES_PER_CELL) * bpe / 8 * cells_global * args.steps / wall / 1e9}
@@ -541,6 +548,7 @@ def main():
                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "frac_of_measured_copy_6290": op_bytes / (op_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                                         "frac_of_this_box_copy": (op_bytes / (op_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
+                                        "frac_of_this_box_oneshot_copy": (op_bytes / (op_ms * 1e-3) / 1e9 / box["hbm_copy_oneshot_GBps"]) if (box and "hbm_copy_oneshot_GBps" in box) else None,
                                         "per_launch_ms_min_median_max": [per[0], per[len(per) // 2], per[-1]],
                                         "algorithmic_bytes_per_launch": op_bytes, "timing": "50 back-to-back launches inside one HIP event pair",
                                         "rocprof_avg_launch_ms": (ks or {}).get(opk + "_mean_ms") if default_workload else None,

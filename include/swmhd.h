@@ -102,6 +102,10 @@ int swmhd_event_destroy(void *event);
 /* Measurement hook: nanoseconds one fp64 wave-instruction occupies a SIMD right now (three waves per SIMD, independent fma chains:
  * 4 cycles of the shader clock the box holds under fp64 load).  Synchronises `stream`.  scratch: >= 8 bytes of device memory. */
 int swmhd_probe_fp64_issue(double *scratch, float *ns_per_wave_instruction, void *stream);
+/* Measurement hook: best-case plain-copy rate of the box, GB/s of bytes read + written: one 16-byte element per thread, workgroups in
+ * address order (the pattern that reaches the guide's 6.29 TB/s; persistent copy kernels -- torch's, hipMemcpy -- reach ~20 % less).
+ * bytes: multiple of 16, >= 4096; `reps` timed launches after 3 warm-up ones.  Synchronises `stream`. */
+int swmhd_probe_copy(void *dst, const void *src, size_t bytes, int reps, float *gbytes_per_s, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Jacobian-form Lorentz force.   Replaces lorentz_force_func_x / lorentz_force_func_y

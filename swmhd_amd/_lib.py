@@ -44,6 +44,8 @@ def _declare(lib):
         getattr(lib, "swmhd_event_" + n).restype = i
     lib.swmhd_probe_fp64_issue.argtypes = [p, C.POINTER(C.c_float), p]
     lib.swmhd_probe_fp64_issue.restype = i
+    lib.swmhd_probe_copy.argtypes = [p, p, C.c_size_t, i, C.POINTER(C.c_float), p]
+    lib.swmhd_probe_copy.restype = i
     for sfx, ft in (("f64", C.c_double), ("f32", C.c_float)):
         for form in ("jacobian", "divergence"):
             f = getattr(lib, f"swmhd_lorentz_{form}_{sfx}")
@@ -110,7 +112,7 @@ def _declare(lib):
 
 
 # every symbol include/swmhd.h declares (tests/test_abi.py checks the .so exports each of them)
-EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry", "swmhd_probe_fp64_issue"] + ["swmhd_event_" + n for n in ("create", "record", "elapsed_ms", "destroy")] + [
+EXPORTS = ["swmhd_version", "swmhd_strerror", "swmhd_tendency_launch_geometry", "swmhd_probe_fp64_issue", "swmhd_probe_copy"] + ["swmhd_event_" + n for n in ("create", "record", "elapsed_ms", "destroy")] + [
     f"swmhd_{name}_{sfx}" for sfx in ("f64", "f32") for name in (
         "lorentz_jacobian", "lorentz_jacobian_rows", "lorentz_divergence", "lorentz_divergence_rows",
         "fill_halo", "fill_halo_periodic", "fill_halo_periodic_multi", "tendencies", "tendencies_rk3", "rk3_substep", "step_rk3", "diagnostics",

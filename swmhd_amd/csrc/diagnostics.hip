@@ -172,3 +172,38 @@ extern "C" int swmhd_probe_fp64_issue(double *scratch, float *ns_per_wave_instru
     *ns_per_wave_instruction = (float)(ms * 1e6 / ((double)iters * 8 * 4 * W));
     return 0;
 }
+
+// ---- measurement hook: the plain-copy rate of this box, best case ---------------------------------------------------------------
+// One 16-byte element per thread, one 4-KB chunk per workgroup, workgroups dispatched in address order: the access pattern that reaches
+// the guide's 6.29 TB/s copy figure (tools/copy_probe.hip: 6.2 TB/s where torch's persistent copy kernel gets 5.0 and hipMemcpy 4.8).
+// Kernels that carry state along a direction (the row-marching ones here) are of the persistent kind; bench.py quotes both rates.
+namespace swmhd {
+namespace {
+typedef float probe_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_probe(const probe_v4 *__restrict__ a, probe_v4 *__restrict__ b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) b[i] = a[i];
+}
+}  // namespace
+}  // namespace swmhd
+
+extern "C" int swmhd_probe_copy(void *dst, const void *src, size_t bytes, int reps, float *gbytes_per_s, void *stream) {
+    if (!dst || !src || !gbytes_per_s || bytes < 4096 || (bytes & 15) || reps < 1) return 1;   // SWMHD_EINVAL
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = bytes / 16;
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return 1;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return 1; }
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(swmhd::k_copy_probe, dim3(blocks), dim3(256), 0, s, (const swmhd::probe_v4 *)src, (swmhd::probe_v4 *)dst, n);
+    (void)hipEventRecord(e0, s);
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(swmhd::k_copy_probe, dim3(blocks), dim3(256), 0, s, (const swmhd::probe_v4 *)src, (swmhd::probe_v4 *)dst, n);
+    (void)hipEventRecord(e1, s);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e != hipSuccess || ms <= 0.f) return e != hipSuccess ? -(int)e : 1;
+    *gbytes_per_s = (float)(2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9);
+    return 0;
+}
