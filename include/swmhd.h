@@ -46,7 +46,10 @@
  *     vh, 7.9e-10 for config 3's h) because at those resolutions the tendency is orders of magnitude smaller than the terms it is the
  *     difference of.  fp32 CAVEAT: where the terms cancel strongly the fp32 tendency carries no significant digits relative to its own
  *     size -- G_h of the 16384^2 Bickley-jet state (mass fluxes u h/dx ~ 650, G_h ~ 3e-4) is off by 0.15 * max|G_h| in fp32, fast or
- *     strict alike (one ulp of a flux).  Use fp32 where 1e-7 of the fluxes is enough; the fp32-vs-fp64 state after 100 steps of that
+ *     strict alike (one ulp of a flux).  The Jacobian-form force takes THIRD differences of A: on a field with a large smooth part
+ *     (A = -0.05 y + perturbation) their fp32 rounding noise grows like eps |A| / dx^3 and stirs the flow once dx <~ 0.08 (the
+ *     reference's 128^2 low_B_low_U run: energy error 3.9 instead of 0.53 by t = 15 in Float32; the divergence form, first differences
+ *     only, is unaffected).  Use fp32 where 1e-7 of the fluxes is enough; the fp32-vs-fp64 state after 100 steps of that
  *     configuration agrees to 9e-5 of the velocity scale (tests/test_fullsize_gpu.py).
  *   Which scheme: the oracle's base right-hand side restates the Oceananigans version the reference ran and is pinned to the reference's
  *     twelve committed energy plots at plot-reading accuracy (tests/test_reference_plots.py); last bits of a Julia
