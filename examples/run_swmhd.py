@@ -9,7 +9,12 @@ g = 9.81, f = 1, RK3, A = 0.5|y| ("uniform B_x") or the two Gaussians, h = 1, th
 (multiplied by h for the conservative variables), dt = 0.01, stop time 30.  Every --every iterations one progress line like the
 reference's (SWMHD_example.jl:47-61: time, iteration, max|u|, max|A|, min h, wall time) and one row of the energies the reference
 sends to NetCDF (:74-77) into --energies (CSV).  --dump-every T writes the fields incl. halos as .npy (the JLD2 writer's role, :80-84).
-The step loop runs through HIP-graph replays (two RK3 steps per replay)."""
+The step loop runs through HIP-graph replays (two RK3 steps per replay).
+
+    python examples/run_swmhd.py --plot-case jacobian_formulation/128x128_two_Gaussians_low_B
+re-runs one of the twelve runs behind the reference's committed energy plots (energy_plots/*/*.png; set-up from the scripts' commented
+alternatives, see tests/plot_cases.py) and prints, beside every energy row, the value read off the plot at that time
+(tests/golden/plot_readings.json) -- the comparison tests/test_reference_plots.py asserts."""
 import argparse, csv, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,7 +32,10 @@ def main():
     ap.add_argument("--energies", default=None, help="CSV file for (time, KE, ME, PE, total)")
     ap.add_argument("--dump-every", type=float, default=0.0, help="model time between field dumps (0 = none)")
     ap.add_argument("--out", default="swmhd_out")
+    ap.add_argument("--plot-case", default=None, help="one of the reference's plotted runs, e.g. jacobian_formulation/64x64_low_B_low_U")
     a = ap.parse_args()
+    if a.plot_case:
+        return plot_case(a)
 
     import torch
     import swmhd_amd as S
@@ -74,6 +82,55 @@ def main():
     if a.energies:
         with open(a.energies, "w", newline="") as f:
             w = csv.writer(f); w.writerow(["time", "kinetic", "magnetic", "potential", "total"]); w.writerows(rows)
+
+
+def plot_case(a):
+    """One of the reference's twelve plotted runs through the HIP engine, the plot's own readings printed beside the run's energies."""
+    import json
+    import swmhd_amd as S
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "plot_readings.json")) as f:
+        R = json.load(f)
+    if a.plot_case not in R:
+        sys.exit("--plot-case must be one of: " + ", ".join(k for k in sorted(R) if not k.startswith("_")))
+    r = R[a.plot_case]
+    form_dir, rest = a.plot_case.split("/")
+    N, ic = int(rest.split("x")[0]), rest.split("_", 1)[1]
+    form = "VectorInvariant" if form_dir.startswith("jacobian") else "Conservative"
+    L, dt = 10.0, 0.01
+    gauss = lambda amp: (lambda X, Y: amp * np.exp(-((X - 0.5) ** 2 + Y ** 2)) - amp * np.exp(-((X + 0.5) ** 2 + Y ** 2)))
+    zero = lambda X, Y: np.zeros_like(X)
+    bcs, topo, u0, v0 = None, ("Periodic", "Periodic", "Flat"), zero, zero
+    if ic == "low_B_low_U":          # divergence_sw_mhd.jl:34,36-37 with the commented GradientBoundaryCondition(-0.05), (Periodic, Bounded)
+        A0, topo = (lambda X, Y: -0.05 * Y), ("Periodic", "Bounded", "Flat")
+        u0, v0 = (lambda X, Y: Y * np.exp(-(X ** 2 + Y ** 2))), (lambda X, Y: -X * np.exp(-(X ** 2 + Y ** 2)))
+        bcs = {"A": S.FieldBoundaryConditions(south=S.GradientBoundaryCondition(-0.05), north=S.GradientBoundaryCondition(-0.05))}
+    else:
+        A0 = gauss(0.1 if ic.endswith("low_B") else 0.5)
+    grid = S.RectilinearGrid(size=(N, N), x=(-L / 2, L / 2), y=(-L / 2, L / 2), topology=topo)
+    m = S.ShallowWaterModel(grid, 9.81, 1.0, formulation=form, boundary_conditions=bcs)
+    n1, n2 = m.names[:2]
+    m.set(**{n1: u0, n2: v0, "h": lambda X, Y: np.ones_like(X), "A": A0})
+    t_end = a.stop_time if a.stop_time != 30.0 else r["times"][-1]
+    step = r["times"][1] - r["times"][0]
+    e0 = None
+    print(f"{a.plot_case}: {form}, {N}x{N}, dt = {dt}, to t = {t_end:g}   [run | plot reading +- tolerance]")
+    t0 = time.perf_counter()
+    for k, t in enumerate(r["times"]):
+        if t > t_end + 1e-9:
+            break
+        if k:
+            m.time_steps(int(round(step / dt)), dt)
+        d = m.diagnostics()
+        e0 = d["total_energy"] if e0 is None else e0
+        vals = dict(kinetic=d["kinetic_energy"], magnetic=d["magnetic_energy"], potential=d["potential_energy"], error_x100=abs(d["total_energy"] - e0) * 100)
+        cells = []
+        for p in ("kinetic", "magnetic", "potential", "error_x100"):
+            rd = r.get(p, [None] * len(r["times"]))[k]
+            ref = "      -      " if rd is None else f"{rd[0] - (490.5 if (p == 'potential' and rd[0] > 400) else 0):9.5f}+-{rd[1]:.5f}"
+            cells.append(f"{p[:3]} {vals[p]:9.5f} | {ref}")
+        print(f"t = {t:5.1f}  " + "   ".join(cells), flush=True)
+    print(f"{m.iteration} iterations in {time.perf_counter() - t0:.2f} s")
 
 
 if __name__ == "__main__":

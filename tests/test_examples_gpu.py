@@ -23,3 +23,13 @@ def test_example_runs(tmp_path, form, ic, me0):
     if me0 is not None:
         assert abs(float(rows[0][2]) - me0) < 2e-3
     assert "Simulation took" in r.stdout and all(math.isfinite(float(x)) for row in rows for x in row)
+
+
+def test_example_reruns_a_plotted_case_beside_its_readings():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "run_swmhd.py"), "--plot-case", "divergence_formulation/64x64_two_Gaussians_high_B"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("t = ")][-1]
+    assert last.startswith("t =  10.0")
+    run, plot = last.split("err")[1].split("|")
+    assert abs(float(run) - float(plot.split("+-")[0])) < 0.05          # 1.19 against the plot's 1.18
