@@ -33,21 +33,19 @@ typedef struct {
     int vhat4;        /* 1: advecting velocity of the vorticity flux by the centred fourth-order interpolant                      */
     int no_cdivU;     /* 1: tracer tendency without the + c div(U) term                                                            */
     int weno_exp;     /* exponent of the weights (2)                                                                               */
-    int upwind_cons;  /* 1: vorticity flux in "conservative" order: reconstruct zeta, multiply by the LOCAL interpolated velocity  */
     double eps;       /* epsilon of the weights (1e-6)                                                                             */
 } oracle_variant_t;
-static oracle_variant_t OV = {0, 0, 0, 0, 0, 2, 0, 1e-6};
+static oracle_variant_t OV = {0, 0, 0, 0, 0, 2, 1e-6};
 
 #include <string.h>
 int oracle_set_variant(const char *name, double v) {
-    if (!strcmp(name, "reset")) { oracle_variant_t d = {0, 0, 0, 0, 0, 2, 0, 1e-6}; OV = d; return 0; }
+    if (!strcmp(name, "reset")) { oracle_variant_t d = {0, 0, 0, 0, 0, 2, 1e-6}; OV = d; return 0; }
     if (!strcmp(name, "rbeta_mirror")) { OV.rbeta_mirror = (int)v; return 0; }
     if (!strcmp(name, "js_weights")) { OV.js_weights = (int)v; return 0; }
     if (!strcmp(name, "vel_beta")) { OV.vel_beta = (int)v; return 0; }
     if (!strcmp(name, "vhat4")) { OV.vhat4 = (int)v; return 0; }
     if (!strcmp(name, "no_cdivU")) { OV.no_cdivU = (int)v; return 0; }
     if (!strcmp(name, "weno_exp")) { OV.weno_exp = (int)v; return 0; }
-    if (!strcmp(name, "upwind_cons")) { OV.upwind_cons = (int)v; return 0; }
     if (!strcmp(name, "eps")) { OV.eps = v; return 0; }
     return 1;
 }

@@ -125,7 +125,7 @@ def read_panel(im, grey, frame, colour, xt_val, yt_val, times):
         top, bot = col.min(), col.max()
         v = ay * (top + bot) / 2 + by
         tol = abs(ay) * max((bot - top + 1) / 2 - 1.0, 1.5)      # a 4-px band read at its centre: >= 1.5 px
-        out.append((float(v), float(tol)))
+        out.append((float(f"{v:.7g}"), float(f"{tol:.4g}")))
     return out, dict(x_per_px=float(ax), y_per_px=float(abs(ay)))
 
 
@@ -151,7 +151,7 @@ def main():
             entry[name + "_scale"] = scale
         result[key] = entry
     with open(OUT, "w") as f:
-        json.dump(result, f, indent=0)
+        f.write("{\n" + ",\n".join(json.dumps(k) + ": " + json.dumps(v, separators=(",", ":")) for k, v in result.items()) + "\n}\n")
     print("wrote", OUT)
 
 
