@@ -33,7 +33,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_COPY_GBS = 6290.0          # the same guide's measured copy rate: every fraction is quoted against both (BASELINE.md sections 3-4)
 TEND_BYTES_PER_CELL = 64       # read u,v,h,A + write 4 tendencies, fp64
-STAGE_BYTES_PER_CELL = (96, 128, 96)   # what the three FUSED stage launches move: + new state; + G- read; last stage stores no G
+STAGE_BYTES_PER_CELL = (64, 128, 96)   # what the three FUSED stage launches move (fast builds): stage 1 reads U0, writes U1 -- no tendency store:
+                                       # stage 2 forms G0 = (U1 - U0)/(dt gamma1) from the two states (swmhd.h SWMHD_GM_IS_PREV_STATE); stage 2
+                                       # reads U1, U0 and writes U2, G1; stage 3 reads U2, G1 and writes U3.  288 B/cell-step (strict: 96/128/96)
 PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 VALU_NS_PER_WAVE_INST = 2.05   # one fp64 wave-instruction per 2.05 ns per SIMD (tools/valu_probe.hip: 4 cycles at ~1.95 GHz under load)
 
@@ -435,7 +437,8 @@ def main():
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE config {args.config}: global grid {Nx}x{Ny_global} ({Nx}x{Ny_local} cells per GPU), periodic, "
                                    f"{form} formulation + {lor}-form Lorentz forcing, {CONFIGS[args.config]['text']}",
-                       "step": "one RK3 time step = 3 fused tendency+substep launches (periodic images gathered on read: no halo launch between stages)",
+                       "step": "one RK3 time step = 3 fused tendency+substep launches (periodic images gathered on read: no halo launch between stages; "
+                               "fast builds: the first stage stores no tendencies, the second forms G- from the two states)",
                        "kernels": "strict (oracle-order)" if args.strict else "fast",
                        "spin_up": "40 untimed steps before the warm-up steps (device clocks settle after ~30 ms of load)",
                        "decomposition": (f"y-slabs x{world} (ring halo exchange, backend {args.backend}, overlapped; "
@@ -458,7 +461,8 @@ def main():
             kcells = Nx * krows
             tend_bytes = TEND_BYTES_PER_CELL * bpe // 8
             achieved = tend_bytes * kcells / (kern_ms * 1e-3) / 1e9
-            fused_bytes = sum(STAGE_BYTES_PER_CELL) / 3.0 * bpe / 8 * kcells
+            stage_bytes = (96, 128, 96) if args.strict else STAGE_BYTES_PER_CELL
+            fused_bytes = sum(stage_bytes) / 3.0 * bpe / 8 * kcells
             kname = "k_tendency_vi_march" if form == "VectorInvariant" else "k_tendency_cons_march"
             roof = {"bound": "hbm", "kernel": kname + " (fused RHS of the 4 prognostic fields incl. Lorentz force + RK3 substep)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -469,15 +473,17 @@ def main():
                     "algorithmic_bytes_per_launch": tend_bytes * kcells, "cells_per_launch": kcells,
                     "avg_launch_ms": kern_ms, "launches_timed": len(ms),
                     "timing": "HIP events around every stage launch inside the timed region, on the launch stream",
-                    "fused_stage": {"bytes_per_cell_stage_1_2_3": [b * bpe // 8 for b in STAGE_BYTES_PER_CELL],
+                    "fused_stage": {"bytes_per_cell_stage_1_2_3": [b * bpe // 8 for b in stage_bytes],
                                     "mean_bytes_per_launch": fused_bytes, "achieved": fused_bytes / (kern_ms * 1e-3) / 1e9,
                                     "frac": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "frac_of_measured_copy_6290": fused_bytes / (kern_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
                                     "frac_of_this_box_copy": (fused_bytes / (kern_ms * 1e-3) / 1e9 / box["hbm_copy_GBps"]) if box else None,
                                     "frac_of_this_box_oneshot_copy": (fused_bytes / (kern_ms * 1e-3) / 1e9 / box["hbm_copy_oneshot_GBps"]) if (box and "hbm_copy_oneshot_GBps" in box) else None,
-                                    "what": "bytes the fused stage launches really move (new state written, G- read in stages 2-3, no G "
-                                            "store in stage 3); `achieved` above stays on the 64-B tendency figure"},
-                    "whole_step_GBps_on_320B": sum(STAGE_BYTES_PER_CELL) * bpe / 8 * cells_global * args.steps / wall / 1e9}
+                                    "what": "bytes the fused stage launches really move (new state written; no G store in stages 1 and 3: "
+                                            "stage 2 takes G- from the two states it reads; G- read in stage 3); `achieved` above stays on the "
+                                            "64-B tendency figure"},
+                    "whole_step_bytes_per_cell": sum(stage_bytes) * bpe // 8,
+                    "whole_step_GBps": sum(stage_bytes) * bpe / 8 * cells_global * args.steps / wall / 1e9}
             # HBM traffic from the PMC counters cannot be collected inside this process: the per-launch figure measured with
             # rocprofv3 --pmc on this same command (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per the gfx950
             # note of the microarchitecture guide) lives under profiles/ and is echoed ONLY while the kernel sources are unchanged.

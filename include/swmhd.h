@@ -76,6 +76,11 @@ extern "C" {
 #define SWMHD_WRAP_Y 32       /*   y mod Ny) instead of the halo cell -- so those halos need not be filled (no halo launch per stage)  */
 #define SWMHD_BOUNDED_X 256    /* tendency entry points: the grid's topology in x / in y is Bounded (default: Periodic).  Reconstructions  */
 #define SWMHD_BOUNDED_Y 512    /*   near the walls use Oceananigans' boundary schemes, the divergence forcing the reference's wall branches */
+#define SWMHD_GM_IS_PREV_STATE 1024 /* swmhd_tendencies_rk3 only (fast builds, periodic): Gm[f] holds the PREVIOUS STATE U- the current state was
+                                    stepped from with G- alone (U = U- + dt gamma- G-), not G- itself; pass zeta / gamma- as `zeta`; the kernel
+                                    forms Unew = U + dt gamma G + zeta (U - U-).  Gm may then alias qnew (each cell reads its own U- before it
+                                    writes Unew): the first RK3 stage need not store its tendencies at all (32 B/cell less HBM traffic per
+                                    step).  Results differ from the G- form by less than one ulp of U.  The step drivers use it.            */
 #define SWMHD_LEAVE_ROOM 64   /* tendency entry points: size the row-marching grid ~5 % short of filling the chip, so that kernels of
                                  another stream (the ring's halo exchange and boundary strips) can start while it runs                */
 

@@ -13,6 +13,7 @@ TILE_KERNEL = 2
 MARCH_KERNEL = 4
 WRAP_X, WRAP_Y = 16, 32
 LEAVE_ROOM = 64
+GM_IS_PREV_STATE = 1024
 BOUNDED_X, BOUNDED_Y = 256, 512
 KERNEL_FLAGS = {None: 0, "auto": 0, "tile": 2, "march": 4}
 PERIODIC, BOUNDED = 0, 1

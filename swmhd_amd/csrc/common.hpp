@@ -65,6 +65,7 @@ struct TendArgs {
     // optional fused RK3 substep (fuse != 0):  Unew[f] = U[f] + dt (gamma G[f] + zeta Gm[f])  written to a SECOND set of
     // fields (neighbouring workgroups still read the old U through their halos); store_G = 0 skips writing G (last stage)
     int fuse, first, store_G;
+    int gm_prev;          // Gm[] holds the previous STATE U- (U = U- + dt gamma- G-), zeta holds zeta/gamma-: Unew = U + dt gamma G + zeta (U - U-)
     int drop_G;           // marching kernels: issue the G stores with an out-of-range offset (the hardware drops them): lets the last RK3
                           // stage run the stage-2 kernel variant where that one has the better register allocation
     int wrap;             // periodic index wrapping of the READS: bit0 = x, bit1 = y -- the kernel takes (x mod Nx, y mod Ny) instead of the
@@ -76,6 +77,11 @@ struct TendArgs {
     T *Unew[4];
     const T *Gm[4];
     T dt, gamma, zeta;
+    T dtg;                // dt * gamma, formed on the host (a uniform fp64 product would sit in a VGPR pair for the whole kernel)
+    T cu, cg;             // the substep in coefficient form, Unew = (U + cu U) + dt gamma G + cg Gm: (0, dt zeta) for Gm = G-, (zeta', -zeta') for
+                          // Gm = previous state (gm_prev).  The stage variant that reads Gm AND stores G (the second RK3 stage) uses this form,
+                          // so that one compiled kernel serves both operands without a branch (a branch there cost the other variants their
+                          // register allocation: 80 B of scratch).
 };
 template <typename T>
 struct Rk3Args {

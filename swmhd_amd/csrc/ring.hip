@@ -267,6 +267,7 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
     }
     int swaps = 0;
     hipError_t e;
+    const bool from_state = !(flags & SWMHD_STRICT);   // fast builds: no tendency store in the first stage (see step_common in swmhd_api.hip)
     // whatever the caller enqueued on its stream so far precedes everything this call puts on the comm stream
     if ((e = hipEventRecord(r->ev_main, s)) != hipSuccess) return hipfail(r, "record", e);
     if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return hipfail(r, "wait", e);
@@ -299,8 +300,12 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
             for (int st = 0; st < 3; ++st) {
                 const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
                 const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+                const bool fs = from_state && st == 1;        // G- of the second stage from the two states (swmhd.h SWMHD_GM_IS_PREV_STATE)
+                if (fs) for (int f = 0; f < 4; ++f) cgm[f] = alt[f];
                 const T *const *pgm = st == 0 ? nullptr : cgm;
-                const int store = st < 2 ? 1 : 0;
+                const int store = st == 1 ? 1 : (st == 0 && !from_state ? 1 : 0);
+                const T zeta_st = fs ? zet[1] / gam[0] : zet[st];
+                const int sflags = fs ? SWMHD_GM_IS_PREV_STATE : 0;
                 const int jb = ilo[st], je = Ny - ilo[st];
                 const bool timed = r->t0.size() < r->tcap;
                 hipEvent_t a = nullptr, b = nullptr;
@@ -309,8 +314,8 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
                     if ((e = hipEventCreateWithFlags(&b, hipEventDisableSystemFence)) != hipSuccess) { (void)hipEventDestroy(a); return bail(hipfail(r, "hipEventCreate", e)); }
                     (void)hipEventRecord(a, s);
                 }
-                int rc = Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st], zet[st],
-                                       store, jb, je, flags | SWMHD_LEAVE_ROOM, (void *)s);
+                int rc = Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st], zeta_st,
+                                       store, jb, je, flags | SWMHD_LEAVE_ROOM | sflags, (void *)s);
                 if (timed) {
                     if (rc) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); }
                     else { (void)hipEventRecord(b, s); r->t0.push_back(a); r->t1.push_back(b); r->trows.push_back(je - jb); }
@@ -321,8 +326,8 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
                 }
                 // boundary rows of this stage, both sides in one launch, behind the exchange (stage 1) / the previous boundary launch
                 if ((rc = swmhd::tendencies_rk3_two_ranges<T>(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, (long)sy, dx, dy, grav, fcor, formulation,
-                                                              lorentz, dt, gam[st], zet[st], store, blo[st], ilo[st], Ny - ilo[st],
-                                                              Ny - blo[st], bflags, (void *)c)))
+                                                              lorentz, dt, gam[st], zeta_st, store, blo[st], ilo[st], Ny - ilo[st],
+                                                              Ny - blo[st], bflags | sflags, (void *)c)))
                     return bail(rc);
                 if (st < 2) {
                     if ((e = hipStreamWaitEvent(c, r->ev_main, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));
@@ -345,11 +350,15 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
         for (int st = 0; st < 3; ++st) {
             const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
             const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+            const bool fs = from_state && st == 1;
+            if (fs) for (int f = 0; f < 4; ++f) cgm[f] = alt[f];
             const T *const *pgm = st == 0 ? nullptr : cgm;
-            const int store = st < 2 ? 1 : 0;
+            const int store = st == 1 ? 1 : (st == 0 && !from_state ? 1 : 0);
+            const T zeta_st = fs ? zet[1] / gam[0] : zet[st];
+            const int sflags = fs ? SWMHD_GM_IS_PREV_STATE : 0;
             auto run = [&](int j0, int j1, hipStream_t on, int extra = 0) {
                 return Api<T>::stage(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation, lorentz, dt, gam[st],
-                                     zet[st], store, j0, j1, flags | extra, (void *)on);
+                                     zeta_st, store, j0, j1, flags | extra | sflags, (void *)on);
             };
             int rc;
             const bool split = r->pending != nullptr;
@@ -372,7 +381,7 @@ int ring_step(swmhd_ring *r, T *const *q, T *const *q_alt, T *const *Ga, T *cons
             if (rc) return bail(rc);
             if (split) {   // both strips in one launch: they sit on the exchange -> strips -> exchange chain that bounds a thin slab
                 if ((rc = swmhd::tendencies_rk3_two_ranges<T>(cq, alt, gn, pgm, Nx, Ny, Hx, Hy, (long)sy, dx, dy, grav, fcor, formulation,
-                                                              lorentz, dt, gam[st], zet[st], store, 0, Hy, Ny - Hy, Ny, flags, (void *)c)))
+                                                              lorentz, dt, gam[st], zeta_st, store, 0, Hy, Ny - Hy, Ny, flags | sflags, (void *)c)))
                     return bail(rc);
                 if ((e = hipEventRecord(r->ev_comm, c)) != hipSuccess) return bail(hipfail(r, "record", e));
                 if ((e = hipStreamWaitEvent(s, r->ev_comm, 0)) != hipSuccess) return bail(hipfail(r, "wait", e));

@@ -103,7 +103,11 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     const int ext = ((flags & (SWMHD_WRAP_Y | SWMHD_BOUNDED_Y)) || Hy < 3) ? 0 : Hy - 3;
     if (j0 < -ext || j1 > Ny + ext || j0 > j1) return SWMHD_EINVAL;
     if (j1b > j0b && (j0b < j1 || j1b > Ny + ext)) return SWMHD_EINVAL;   // (internal: second row range of the slab driver, above the first)
-    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_EINVAL;
+    if (flags & ~(SWMHD_STRICT | SWMHD_TILE_KERNEL | SWMHD_MARCH_KERNEL | SWMHD_WRAP_X | SWMHD_WRAP_Y | SWMHD_LEAVE_ROOM | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y | SWMHD_GM_IS_PREV_STATE)) return SWMHD_EINVAL;
+    if (flags & SWMHD_GM_IS_PREV_STATE) {   // fast, periodic, fused stage with a G- operand only (a Bounded grid's frame launch would read cells the first launch has overwritten)
+        if (!rk || !rk->Gm) return SWMHD_EINVAL;
+        if (flags & (SWMHD_STRICT | SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) return SWMHD_ENOTSUP;
+    }
     if (((flags & SWMHD_BOUNDED_X) && (flags & SWMHD_WRAP_X)) || ((flags & SWMHD_BOUNDED_Y) && (flags & SWMHD_WRAP_Y))) return SWMHD_EINVAL;
     if ((flags & (SWMHD_BOUNDED_X | SWMHD_BOUNDED_Y)) && (flags & SWMHD_MARCH_KERNEL)) return SWMHD_ENOTSUP;   // walls: LDS-tiled kernel only
     if (((flags & SWMHD_WRAP_X) && Hx > Nx) || ((flags & SWMHD_WRAP_Y) && Hy > Ny)) return SWMHD_EHALO;   // one period must cover the halo
@@ -122,6 +126,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     a.dx = dx; a.dy = dy; a.rdx = T(1) / dx; a.rdy = T(1) / dy; a.grav = grav; a.fcor = fcor; a.j0 = j0; a.j1 = j1;
     a.j0b = j1b > j0b ? j0b : 0; a.j1b = j1b > j0b ? j1b : 0;
     a.fuse = 0; a.first = 0; a.store_G = 1; a.drop_G = 0; a.dt = a.gamma = a.zeta = T(0);
+    a.gm_prev = (flags & SWMHD_GM_IS_PREV_STATE) ? 1 : 0; a.cu = a.cg = a.dtg = T(0);
     a.wrap = ((flags & SWMHD_WRAP_X) ? 1 : 0) | ((flags & SWMHD_WRAP_Y) ? 2 : 0);
     a.leave_room = (flags & SWMHD_LEAVE_ROOM) ? 1 : 0;
     a.edge_cols = 0;
@@ -130,6 +135,7 @@ int tend_common(const T *q1, const T *q2, const T *h, const T *A, T *G1, T *G2, 
     for (int f = 0; f < 4; ++f) { a.Unew[f] = nullptr; a.Gm[f] = nullptr; }
     if (rk) {
         a.fuse = 1; a.first = rk->Gm ? 0 : 1; a.store_G = rk->store_G; a.dt = rk->dt; a.gamma = rk->gamma; a.zeta = rk->zeta;
+        a.cu = a.gm_prev ? rk->zeta : T(0); a.cg = a.gm_prev ? -rk->zeta : rk->dt * rk->zeta; a.dtg = rk->dt * rk->gamma;
         for (int f = 0; f < 4; ++f) { a.Unew[f] = rk->Unew[f] + off; a.Gm[f] = rk->Gm ? rk->Gm[f] + off : nullptr; }
     }
     hipStream_t s = (hipStream_t)stream;
@@ -182,12 +188,19 @@ int step_common(T *const *q, T *const *q_alt, T *const *Ga, T *const *Gb, int Nx
         cur[f] = q[f]; alt[f] = q_alt[f]; gn[f] = Ga[f]; gm[f] = Gb[f];
     }
     int swaps = 0;
+    // Fast builds: the second stage takes G- = (U1 - U0) / (dt gamma1) from the two states (SWMHD_GM_IS_PREV_STATE) -- U0 lives in the
+    // very buffer the stage writes U2 to -- so the first stage stores no tendencies: 288 instead of 320 B/cell-step.
+    const bool from_state = !(flags & SWMHD_STRICT);
     for (int n = 0; n < nsteps; ++n)
         for (int st = 0; st < 3; ++st) {
             const T *cq[4] = {cur[0], cur[1], cur[2], cur[3]};
             const T *cgm[4] = {gm[0], gm[1], gm[2], gm[3]};
+            const bool fs = from_state && st == 1;
+            if (fs) for (int f = 0; f < 4; ++f) cgm[f] = alt[f];
+            const int store = st == 1 ? 1 : (st == 0 && !from_state ? 1 : 0);
             int rc = tend_rk3_common<T>(cq, alt, gn, st == 0 ? nullptr : cgm, Nx, Ny, Hx, Hy, sy, dx, dy, grav, fcor, formulation,
-                                        lorentz, dt, gam[st], zet[st], st < 2 ? 1 : 0, 0, Ny, flags, stream);
+                                        lorentz, dt, gam[st], fs ? zet[1] / gam[0] : zet[st], store, 0, Ny,
+                                        flags | (fs ? SWMHD_GM_IS_PREV_STATE : 0), stream);
             if (rc) return rc;
             for (int f = 0; f < 4; ++f) { T *t = cur[f]; cur[f] = alt[f]; alt[f] = t; t = gn[f]; gn[f] = gm[f]; gm[f] = t; }
             ++swaps;

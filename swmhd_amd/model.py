@@ -16,6 +16,8 @@ from .fields import Field, _SFX, _stream_ptr
 from .grid import Center, Face
 
 VectorInvariantFormulation, ConservativeFormulation = "VectorInvariant", "Conservative"
+import os as _os
+_FROM_STATE = _os.environ.get("SWMHD_FROM_STATE", "1") != "0"      # (A/B knob for the Python-driven stages; the C step drivers always use it in fast builds)
 RK3_GAMMA = (8.0 / 15.0, 5.0 / 12.0, 3.0 / 4.0)
 RK3_ZETA = (0.0, -17.0 / 60.0, -5.0 / 12.0)
 
@@ -287,13 +289,21 @@ class ShallowWaterModel:
         qn = _lib.ptr_array([self._alt[n].ptr for n in self.names])
         Gn = _lib.ptr_array([f.ptr for f in self.Gn])
         Gm = _lib.ptr_array([f.ptr for f in self.Gm]) if stage > 0 else None
+        # Fast periodic builds: the second stage takes G- = (U1 - U0) / (dt gamma1) from the two states -- U0 is still in the buffer this
+        # stage writes U2 to -- so the first stage stores no tendencies (swmhd.h SWMHD_GM_IS_PREV_STATE; 288 instead of 320 B/cell-step).
+        from_state = not self.strict and not any(self._bounded) and _FROM_STATE
+        zeta, store = RK3_ZETA[stage], (1 if stage < 2 else 0)
+        if from_state and stage == 0:
+            store = 0
+        if from_state and stage == 1:
+            Gm, zeta, extra_flags = qn, RK3_ZETA[1] / RK3_GAMMA[0], extra_flags | _lib.GM_IS_PREV_STATE
         f = getattr(self._L, f"swmhd_tendencies_rk3_{self.sfx}")
         timed = self.tendency_events is not None and 2 * (j1 - j0) > g.Ny    # whole grid, or the interior launch of a slab
         if timed:
             e0, e1 = _lib.TimingEvent(), _lib.TimingEvent()
             e0.record()
         rc = f(q, qn, Gn, Gm, g.Nx, g.Ny, g.Hx, g.Hy, self._raw_fields[0].stride_y, g.dx, g.dy, self.g, self.f, self.form_code,
-               self.lorentz_code, dt, RK3_GAMMA[stage], RK3_ZETA[stage], 1 if stage < 2 else 0, j0, j1,
+               self.lorentz_code, dt, RK3_GAMMA[stage], zeta, store, j0, j1,
                self._flags | self._rwrap | extra_flags, _stream_ptr())
         if timed:
             e1.record()

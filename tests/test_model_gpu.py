@@ -571,3 +571,45 @@ def test_rows_reaching_into_a_deep_halo(swmhd, form, kernel, dtype):
     EINVAL = 1
     assert run(-7, Ny)[0] == EINVAL and run(0, Ny + 7)[0] == EINVAL
     assert run(-1, Ny, flags | L.WRAP_Y)[0] == EINVAL              # wrapped y: no rows outside the interior
+
+
+@pytest.mark.parametrize("form", ["VectorInvariant", "Conservative"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("N", [96, 1024])
+def test_second_stage_with_the_previous_state_as_operand(swmhd, form, dtype, N):
+    """SWMHD_GM_IS_PREV_STATE (swmhd.h): the second RK3 stage given U0 instead of G0 -- U1 = U0 + dt gamma1 G0, zeta passed as
+    zeta2 / gamma1, U0 living in the buffer the stage writes U2 to -- equals the classic call within an ulp of the state, on the
+    LDS-tiled (N = 96) and the row-marching / packed-fp32 (N = 1024) kernels; and it is refused for strict and Bounded calls."""
+    import ctypes
+    S, L = swmhd, swmhd._lib
+    from test_model_oracle import hf, uf, vf, Af, Lx, Ly
+    g = S.RectilinearGrid(size=(N, N), x=(0, Lx), y=(0, Ly))
+    m = S.ShallowWaterModel(g, 9.81, 1.0, formulation=form, dtype=dtype)
+    if form == "VectorInvariant":
+        m.set(u=uf, v=vf, h=hf, A=Af)
+    else:
+        m.set(uh=lambda X, Y: hf(X, Y) * uf(X, Y), vh=lambda X, Y: hf(X, Y) * vf(X, Y), h=hf, A=Af)
+    dt = 2e-4 if N > 512 else 2e-3
+    sfx = m.sfx
+    f = getattr(L.lib(), f"swmhd_tendencies_rk3_{sfx}")
+    mk = lambda: [S.Field(g, dtype=dtype) for _ in range(4)]
+    U0 = [x for x in m.fields]
+    U1, G0, G1a, G1b, U2a = mk(), mk(), mk(), mk(), mk()
+    P = lambda fl: L.ptr_array([x.ptr for x in fl])
+    flags = L.WRAP_X | L.WRAP_Y
+    args = (g.Nx, g.Ny, g.Hx, g.Hy, U0[0].stride_y, g.dx, g.dy, 9.81, 1.0, m.form_code, m.lorentz_code)
+    g1, g2, z2 = 8.0 / 15.0, 5.0 / 12.0, -17.0 / 60.0
+    L.check(f(P(U0), P(U1), P(G0), None, *args, dt, g1, 0.0, 1, 0, g.Ny, flags, None), "stage 1")
+    L.check(f(P(U1), P(U2a), P(G1a), P(G0), *args, dt, g2, z2, 1, 0, g.Ny, flags, None), "stage 2, classic")
+    # previous-state form: the new state goes INTO the buffer that holds U0
+    U2b = [S.Field(g, dtype=dtype, data=x.data.clone()) for x in U0]
+    L.check(f(P(U1), P(U2b), P(G1b), P(U2b), *args, dt, g2, z2 / g1, 1, 0, g.Ny, flags | L.GM_IS_PREV_STATE, None), "stage 2, previous state")
+    torch.cuda.synchronize()
+    I = g.interior
+    eps = np.finfo(np.float64 if dtype == torch.float64 else np.float32).eps
+    for a, b, ga, gb in zip(U2a, U2b, G1a, G1b):
+        A_, B_ = a.numpy()[I].astype(np.float64), b.numpy()[I].astype(np.float64)
+        assert np.isfinite(B_).all() and np.abs(A_ - B_).max() <= 4 * eps * np.abs(A_).max()
+        assert np.array_equal(ga.numpy()[I], gb.numpy()[I])                 # the tendencies themselves do not depend on the operand
+    assert f(P(U1), P(U2b), P(G1b), P(U2b), *args, dt, g2, z2 / g1, 1, 0, g.Ny, flags | L.GM_IS_PREV_STATE | L.STRICT, None) == 3     # SWMHD_ENOTSUP
+    assert f(P(U1), P(U2b), P(G1b), None, *args, dt, g2, z2 / g1, 1, 0, g.Ny, flags | L.GM_IS_PREV_STATE, None) == 1                  # no operand: SWMHD_EINVAL

@@ -29,7 +29,7 @@ B = {f: json.loads(open(os.path.join(P, f + ".json")).read().strip().splitlines(
 v = lambda f: f"{B[f]['value'] / 1e3:.1f} ({B[f]['ms_per_step']:.3f} ms)"
 tr = B["bench_default"]["roofline"].get("traffic")
 lines = (f"`bench.py` lines (`profiles/r03/bench_*.json`): default {v('bench_default')}"
-         + (f", `traffic` {tr / 1e9:.2f} GB per launch = {tr / (sum((96, 128, 96)) / 3 * 4096 * 4096):.2f}× the 96/128/96-byte mean the fused stages move" if tr else "")
+         + (f", `traffic` {tr / 1e9:.2f} GB per launch = {tr / (sum((64, 128, 96)) / 3 * 4096 * 4096):.2f}× the 64/128/96-byte mean the fused stages move" if tr else "")
          + f"; `--formulation Conservative` {v('bench_cons')}; `--force-ring` {v('bench_ring')} — ring of one rank through RCCL, deep-halo schedule"
          + (f", its `companion` run {B['bench_ring']['companion']['ms_per_step']:.3f} ms" if "companion" in B["bench_ring"] else "")
          + f"; `--config 5` {v('bench_c5f64')} and `--config 5 --dtype f32` {v('bench_c5f32')}; `--config 4` (the whole 8192² grid on one GPU) {v('bench_c4')}.\n")

@@ -167,7 +167,7 @@ def main():
                 tot.append(e["hbm_bytes_corrected"])
         out["hbm_bytes_per_launch_corrected"] = mean(tot)
         cells = geo["Nx"] * geo["rows"]
-        out["algorithmic_bytes_per_launch"] = {"tendency_64B": 64 * cells, "fused_stage_mean_(96+128+96)/3": 320 / 3 * cells}
+        out["algorithmic_bytes_per_launch"] = {"tendency_64B": 64 * cells, "fused_stage_mean_(64+128+96)/3": 288 / 3 * cells}
         json.dump(out, open(os.path.join(a.out, "tendency_pmc_traffic.json"), "w"), indent=1)
     print("wrote", sorted(os.listdir(a.out)))
 
