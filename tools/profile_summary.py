@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from swmhd_amd import _lib  # noqa: E402
 
-MODE_STAGE = {"5": "stage1", "7": "stage2", "3": "stage3", "4": "tendency_only"}
+MODE_STAGE = {"1": "stage1", "7": "stage2", "3": "stage3", "4": "tendency_only"}   # stage 1 stores no tendencies since round 3 (MODE 1; it was MODE 5)
 
 
 def kernel_key(name):
@@ -75,12 +75,12 @@ def main():
             stage = []
             for r in csv.DictReader(open(tr)):
                 k, mode = kernel_key(r["Kernel_Name"])
-                if k and k.startswith("k_tendency") and mode in ("5", "7", "3"):
+                if k and k.startswith("k_tendency") and mode in ("1", "7", "3"):
                     stage.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, mode))
             stage.sort()
             timed = stage[-3 * a.steps:]
             out["tendency_stage_mean_ms"] = mean([d for _, d, _ in timed]) / 1e3
-            out["tendency_stage_mean_ms_by_stage"] = {MODE_STAGE[m]: mean([d for _, d, mm in timed if mm == m]) / 1e3 for m in ("5", "7", "3")}
+            out["tendency_stage_mean_ms_by_stage"] = {MODE_STAGE[m]: mean([d for _, d, mm in timed if mm == m]) / 1e3 for m in ("1", "7", "3")}
             out["tendency_stage_mean_note"] = f"mean over the last {len(timed)} fused-stage dispatches (= the timed region of the run)"
         json.dump(out, open(os.path.join(a.out, "fullstep_kernel_stats.json"), "w"), indent=1)
         bj = os.path.join(a.raw, "stats_bench.json")
@@ -123,7 +123,7 @@ def main():
             f64 = sum(e.get("SQ_INSTS_VALU_" + t + "_F64", 0.0) for t in ("ADD", "MUL", "FMA", "TRANS"))
             e["fp64_insts_per_wave_row"] = f64 / wave_rows
             out["by_stage"][MODE_STAGE.get(mode, "mode" + mode)] = e
-            if mode in ("5", "7", "3"):
+            if mode in ("1", "7", "3"):
                 per_row.append(e["valu_insts_per_wave_row"])
         out["valu_insts_per_wave_row"] = mean(per_row)
         out["note"] = ("SQ_INSTS_VALU of one launch / (strips x waves per workgroup x rows): all VALU instructions incl. the per-segment prologue, "
@@ -163,7 +163,7 @@ def main():
             fe, wr = mean(fa[key]["FETCH_SIZE"]) * 1024, mean(wa[key]["WRITE_SIZE"]) * 1024
             e = {"FETCH_SIZE_bytes_raw": fe, "WRITE_SIZE_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr, "dispatches": len(fa[key]["FETCH_SIZE"])}
             out["by_stage"][MODE_STAGE.get(mode, "mode" + mode)] = e
-            if mode in ("5", "7", "3"):
+            if mode in ("1", "7", "3"):
                 tot.append(e["hbm_bytes_corrected"])
         out["hbm_bytes_per_launch_corrected"] = mean(tot)
         cells = geo["Nx"] * geo["rows"]
