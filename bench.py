@@ -511,10 +511,12 @@ def main():
                     ipr = vp["valu_insts_per_wave_row"]
                     floor_ms = ipr * wave_rows / (geo["cus"] * 4) * valu["ns_per_wave_instruction_per_simd"] * 1e-6
                     valu.update({"valu_insts_per_wave_row": ipr, "floor_ms": floor_ms, "frac_of_floor": floor_ms / kern_ms})
-                    stream_ms = fused_bytes / 5.1e12 * 1e3     # tools/stream_probe2.hip: what this access pattern streams at
+                    rate = (box or {}).get("hbm_copy_GBps", 5100.0) * 1e9     # what a persistent kernel streams at on this box (torch's copy)
+                    stream_ms = fused_bytes / rate * 1e3
                     roof["binding_bound"] = "fp64-valu" if floor_ms >= stream_ms else "hbm-streaming"
-                    roof["binding_bound_note"] = (f"VALU floor {floor_ms:.3f} ms vs streaming floor {stream_ms:.3f} ms for the fused-stage bytes "
-                                                  "at the 5.1 TB/s this row-marching access pattern reaches; the 64-B HBM figure would need "
+                    roof["binding_bound_note"] = (f"mean over the three stage launches: fp64 issue floor {floor_ms:.3f} ms vs {stream_ms:.3f} ms for the "
+                                                  f"fused-stage bytes at this box's persistent-copy rate ({rate / 1e12:.2f} TB/s); stage 1 (64 B/cell) sits on "
+                                                  "the first, stage 2 (128 B/cell) on the second; the 64-B HBM figure at 8 TB/s would need "
                                                   f"{tend_bytes * kcells / 8e12 * 1e3:.3f} ms")
                 roof["valu"] = valu
             line["roofline"] = roof
