@@ -83,3 +83,21 @@ def test_initial_energies_low_B_low_U(swmhd):
 
 
 # (The dynamic pins -- KE / ME / PE / |E - E0| time series of all twelve plotted runs -- are tests/test_reference_plots.py.)
+
+
+def test_measurement_probes_return_sane_numbers(swmhd):
+    """swmhd_probe_fp64_issue / swmhd_probe_copy (bench.py's `box` block): an MI355X issues one fp64 wave-instruction per SIMD every
+    4 cycles of a 1.4-2.4 GHz clock and copies at 3-8 TB/s; bad arguments are refused."""
+    import ctypes
+    L = swmhd._lib.lib()
+    scratch = torch.zeros(8, dtype=torch.float64, device="cuda")
+    ns = ctypes.c_float(0)
+    assert L.swmhd_probe_fp64_issue(scratch.data_ptr(), ctypes.byref(ns), None) == 0
+    assert 1.6 < ns.value < 3.0, ns.value
+    src = torch.ones(1 << 25, dtype=torch.float64, device="cuda")       # 256 MiB
+    dst = torch.zeros_like(src)
+    gb = ctypes.c_float(0)
+    assert L.swmhd_probe_copy(dst.data_ptr(), src.data_ptr(), src.numel() * 8, 5, ctypes.byref(gb), None) == 0
+    assert 3000 < gb.value < 9000 and torch.equal(dst, src), gb.value
+    assert L.swmhd_probe_copy(dst.data_ptr(), src.data_ptr(), 100, 5, ctypes.byref(gb), None) == 1          # not a multiple of 16 / too small
+    assert L.swmhd_probe_fp64_issue(None, ctypes.byref(ns), None) == 1
